@@ -1,0 +1,166 @@
+/*
+ * rt_hip.h -- C-ABI device layer of the MI355X path tracer.
+ *
+ * This is the boundary between the C host code (raytracer.h and friends) and
+ * the hand-written HIP kernels.  It takes the place of the reference's OpenCL
+ * plumbing (reference: include/parallel.h:15-68, src/parallel.c) and of its
+ * clSetKernelArg / clEnqueueNDRangeKernel call sites: plain pointers and sizes
+ * only, no C++ or torch types.  Every function is fatal on a device error
+ * (message on stderr, exit(1)) -- the reference's ASRT_CL convention
+ * (src/debug.c:46-53) without the wait on stdin.
+ *
+ * All work of one rt_device is issued to that device's single in-order stream
+ * (the reference uses one in-order command queue, src/parallel.c:159-174).
+ * Launch functions return as soon as the kernel is queued; rt_device_sync or a
+ * blocking download orders the host behind them.
+ */
+#ifndef RT_HIP_H
+#define RT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *rt_mem;                 /* device pointer (replaces cl_mem) */
+typedef struct rt_device rt_device;   /* device ordinal + stream (replaces cl_context/cl_command_queue) */
+
+typedef struct rt_device_props {
+    char name[128];
+    int compute_units;       /* replaces num_multiprocessors, src/parallel.c:176-247 */
+    int wave_size;           /* replaces simt_size */
+    int max_waves_per_cu;
+    size_t global_mem_bytes;
+    size_t lds_bytes_per_cu;
+} rt_device_props;
+
+/* ---- device, memory (src/parallel.c:93-174, 282-442) -------------------- */
+int        rt_device_count(void);
+rt_device *rt_device_open(int ordinal);                 /* create_context */
+void       rt_device_close(rt_device *dev);
+void       rt_device_get_props(rt_device *dev, rt_device_props *out);   /* cl_info */
+void       rt_device_sync(rt_device *dev);              /* clFinish */
+void      *rt_device_stream(rt_device *dev);            /* hipStream_t, for callers that record their own events */
+int        rt_device_ordinal(rt_device *dev);
+
+rt_mem rt_mem_alloc(rt_device *dev, size_t bytes);      /* clCreateBuffer */
+void   rt_mem_free(rt_device *dev, rt_mem m);
+void   rt_mem_upload(rt_device *dev, rt_mem dst, const void *src, size_t bytes);   /* blocking write */
+void   rt_mem_download(rt_device *dev, void *dst, rt_mem src, size_t bytes);       /* blocking read, retrieve_buf */
+void   rt_mem_zero(rt_device *dev, rt_mem m, size_t bytes);                        /* zero_buffer (queued) */
+void   rt_mem_copy(rt_device *dev, rt_mem dst, rt_mem src, size_t bytes);          /* clEnqueueCopyBuffer (queued) */
+
+/* ---- timing with HIP events on the device's stream ---------------------- */
+enum {
+    RT_K_GENERATE_RAYS = 0, RT_K_KD_INTERSECT, RT_K_SPATH_INIT, RT_K_SPATH_TRACE, RT_K_XORSHIFT,
+    RT_K_SPATH_ITERATION, RT_K_RESOLVE_AVG, RT_K_CAST_RAYS, RT_K_PATH_TRACE, RT_K_F_AVERAGE,
+    RT_K_F_TO_BYTE, RT_K_COUNT
+};
+/* When enabled, every launch below is bracketed by two events; the totals are
+   read back (after a sync) with rt_timing_get and cleared with rt_timing_reset. */
+void rt_timing_enable(rt_device *dev, int on);
+void rt_timing_reset(rt_device *dev);
+void rt_timing_get(rt_device *dev, int kernel_id, uint64_t *launches, double *total_ms);
+const char *rt_kernel_name(int kernel_id);
+
+/* ---- scene data as the kernels see it ------------------------------------ */
+/* Flattened kd-tree (built by kd_tree_flatten, kdtree.h).
+ *   nodes      8 bytes each {u32 w0, u32 w1}.
+ *              interior: w0 = float bits of the split position, w1 = right
+ *              child index << 2 | axis (0..2); the left child is the next node.
+ *              leaf:     w1 & 3 == 3, w1 >> 2 = triangle count, w0 = first slot
+ *              in leaf_tris.
+ *   leaf_tris  48 bytes per slot, leaf order (a triangle referenced by several
+ *              leaves is stored once per leaf): {v0.xyz, index offset as u32 bits},
+ *              {v1-v0, 0}, {v2-v0, 0}.
+ *   tri_shade  64 bytes per triangle, indexed by index offset / 3:
+ *              {n0.xyz, colour.r}, {n1.xyz, colour.g}, {n2.xyz, colour.b},
+ *              {reflectivity, 0, 0, 0}.
+ * Replaces the serialised blob + index/vertex/normal image buffers that
+ * kdtree_intersection and the shading kernels gather from
+ * (src/kernels/kdtree.cl:49-65,263-277; src/kernels/path.cl:160-171). */
+typedef struct rt_kd_view {
+    rt_mem nodes;
+    rt_mem leaf_tris;
+    rt_mem tri_shade;
+    uint32_t num_nodes;
+    uint32_t num_leaf_slots;
+    uint32_t num_tris;
+    uint32_t root_is_leaf;
+    float scene_min[3];      /* SCENE_MIN / SCENE_MAX of src/raytracer.c:53-64 */
+    float scene_max[3];
+} rt_kd_view;
+
+/* Original (un-flattened) scene arrays for the brute-force integrators
+ * (src/kernels/collision.cl:240-285,382-468). */
+typedef struct rt_scene_view {
+    rt_mem idx4;          /* int[4] per index {v, vn, vt, mesh} */
+    rt_mem verts4;        /* float[4] per vertex */
+    rt_mem normals4;      /* float[4] per normal */
+    rt_mem meshes;        /* 128-byte mesh records */
+    rt_mem materials;     /* 32-byte material records */
+    rt_mem spheres;       /* 32-byte sphere records */
+    rt_mem planes;        /* 48-byte plane records */
+    uint32_t num_meshes, num_spheres, num_planes, num_materials;
+} rt_scene_view;
+
+/* Per-pixel state of the split path tracer (src/spath_raytracer.c:49-113),
+ * structure-of-arrays, 16 bytes per element unless noted:
+ *   ray_o/ray_d        current ray origin / direction (xyz, w unused)
+ *   origin_o/origin_d  saved primary ray
+ *   hits               {index offset u32, t, u, v} of the current ray
+ *   source_hits        saved primary hit
+ *   prog_a             {mask.xyz, sample_num as u32 bits}
+ *   prog_b             {accum.xyz, bounce_num as u32 bits}
+ *   random             u32 per pixel
+ *   out_tex            float4 accumulation {sum.xyz, sample count} */
+typedef struct rt_spath_buffers {
+    rt_mem ray_o, ray_d, origin_o, origin_d, hits, source_hits, prog_a, prog_b, random, out_tex;
+} rt_spath_buffers;
+
+/* ---- kernel launches ------------------------------------------------------ */
+/* generate_rays (src/kernels/ray.cl:109-133; host src/raytracer.c:182-206).
+   Rows [y0, y0+h) of a frame full_h high; tan_half_fov is tanf(40 deg). */
+void rt_k_generate_rays(rt_device *dev, rt_mem ray_o, rt_mem ray_d, uint32_t w, uint32_t h,
+                        uint32_t y0, uint32_t full_h, float tan_half_fov);
+
+/* kdtree_intersection (src/kernels/kdtree.cl:90-321; host src/spath_raytracer.c:136-171). */
+void rt_k_kd_intersect(rt_device *dev, const rt_kd_view *kd, rt_mem ray_o, rt_mem ray_d, rt_mem hits, uint32_t n);
+
+/* segmented_path_trace_init (src/kernels/path.cl:36-113; host src/spath_raytracer.c:280-316). */
+void rt_k_spath_init(rt_device *dev, const rt_kd_view *kd, const rt_spath_buffers *b, uint32_t w, uint32_t h,
+                     uint32_t y0, uint32_t random_value);
+
+/* segmented_path_trace (src/kernels/path.cl:115-258; host src/spath_raytracer.c:318-353). */
+void rt_k_spath_trace(rt_device *dev, const rt_kd_view *kd, const rt_spath_buffers *b, uint32_t n, uint32_t random_value);
+
+/* xorshift_batch (src/kernels/path.cl:421-426; host src/spath_raytracer.c:237-250). */
+void rt_k_xorshift(rt_device *dev, rt_mem random, uint32_t n);
+
+/* One whole render iteration -- xorshift_batch, kdtree_intersection and
+   segmented_path_trace for every pixel -- as a single launch
+   (the three launches + clFinish of src/spath_raytracer.c:364-385). */
+void rt_k_spath_iteration(rt_device *dev, const rt_kd_view *kd, const rt_spath_buffers *b, uint32_t n, uint32_t random_value);
+
+/* f_buffer_to_byte_buffer_avg (src/kernels/path.cl:428-444; host src/spath_raytracer.c:252-277). */
+void rt_k_resolve_avg(rt_device *dev, rt_mem out_u32, rt_mem out_tex, uint32_t n);
+
+/* cast_ray_test (src/kernels/ray.cl:17-105; host src/ss_raytracer.c:7-56). */
+void rt_k_cast_rays(rt_device *dev, const rt_scene_view *sc, rt_mem out_u32, rt_mem ray_o, rt_mem ray_d, uint32_t n);
+
+/* path_trace (src/kernels/path.cl:260-366; host src/path_raytracer.c:28-82). */
+void rt_k_path_trace(rt_device *dev, const rt_scene_view *sc, rt_mem out_tex, rt_mem ray_d, uint32_t w, uint32_t h,
+                     const float cam_pos[3], uint32_t magic);
+
+/* f_buffer_average (src/kernels/path.cl:394-419; host src/path_raytracer.c:85-109). */
+void rt_k_f_buffer_average(rt_device *dev, rt_mem out_tex, rt_mem fresh, uint32_t n, uint32_t sample);
+
+/* f_buffer_to_byte_buffer (src/kernels/path.cl:447-458; host src/path_raytracer.c:111-144). */
+void rt_k_f_to_byte(rt_device *dev, rt_mem out_u32, rt_mem tex, uint32_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_HIP_H */

@@ -1,0 +1,194 @@
+/*
+ * host_spath.c -- split kd-tree path tracer driver: one bounce of every
+ * pixel's path per render call.  reference: src/spath_raytracer.c:15-436.
+ *
+ * The reference synchronises the host after each of its three launches per
+ * iteration and rewrites a small buffer in between; here an iteration is queued
+ * without waiting (one fused launch by default) and the host only blocks when
+ * the frame is resolved and read back, every resolve_interval iterations and
+ * at completion.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "kdtree.h"
+#include "raytracer.h"
+#include "spath_raytracer.h"
+
+static uint32_t splitmix32(uint32_t seed, uint32_t index)
+{
+    uint32_t z = index + seed * 0x9E3779B9u + 0x9E3779B9u;
+    z = (z ^ (z >> 16)) * 0x85EBCA6Bu;
+    z = (z ^ (z >> 13)) * 0xC2B2AE35u;
+    return z ^ (z >> 16);
+}
+
+/* the per-launch random_value (rand() in the reference, src/spath_raytracer.c:283,321) */
+static uint32_t next_random_value(spath_raytracer_context *c)
+{
+    if (c->rng_mode == RT_RNG_SPLITMIX) return splitmix32(c->rng_seed + 1u, c->rng_launch++);
+    c->rng_launch++;
+    return (uint32_t)rand();
+}
+
+void spath_raytracer_fill_buffers(spath_raytracer_context *c, rt_spath_buffers *b)
+{
+    b->ray_o = c->rctx->cl_ray_buffer;
+    b->ray_d = c->rctx->cl_ray_dir_buffer;
+    b->origin_o = c->cl_path_ray_origin_buffer;
+    b->origin_d = c->cl_path_ray_origin_dir_buffer;
+    b->hits = c->cl_path_collision_result_buffer;
+    b->source_hits = c->cl_path_origin_collision_result_buffer;
+    b->prog_a = c->cl_spath_progress_buffer;
+    b->prog_b = c->cl_spath_progress_b_buffer;
+    b->random = c->cl_random_buffer;
+    b->out_tex = c->cl_path_output_buffer;
+}
+
+/* reference: src/spath_raytracer.c:39-116 */
+spath_raytracer_context *init_spath_raytracer_context(struct _rt_ctx *rctx)
+{
+    spath_raytracer_context *c = (spath_raytracer_context *)calloc(1, sizeof(spath_raytracer_context));
+    rt_device *dev = rctx->rcl->device;
+    const size_t n = (size_t)rctx->width * rctx->height;
+    c->rctx = rctx;
+    c->up_to_date = false;
+    c->cl_path_output_buffer = rt_mem_alloc(dev, n * sizeof(vec4));
+    c->cl_path_ray_origin_buffer = rt_mem_alloc(dev, n * sizeof(vec4));
+    c->cl_path_ray_origin_dir_buffer = rt_mem_alloc(dev, n * sizeof(vec4));
+    c->cl_path_collision_result_buffer = rt_mem_alloc(dev, n * sizeof(kd_tree_collision_result));
+    c->cl_path_origin_collision_result_buffer = rt_mem_alloc(dev, n * sizeof(kd_tree_collision_result));
+    c->cl_random_buffer = rt_mem_alloc(dev, n * sizeof(unsigned int));
+    c->random_buffer = (unsigned int *)malloc(n * sizeof(unsigned int));
+    c->cl_spath_progress_buffer = rt_mem_alloc(dev, n * sizeof(vec4));
+    c->cl_spath_progress_b_buffer = rt_mem_alloc(dev, n * sizeof(vec4));
+    rt_mem_zero(dev, c->cl_spath_progress_buffer, n * sizeof(vec4));
+    rt_mem_zero(dev, c->cl_spath_progress_b_buffer, n * sizeof(vec4));
+    c->cl_bad_api_design_buffer = NULL;
+    c->rng_mode = RT_RNG_LIBC;
+    c->rng_seed = 1;
+    c->resolve_interval = 50;        /* reference: src/spath_raytracer.c:389-390 */
+    c->separate_kernels = 0;
+    c->quiet = false;
+    return c;
+}
+
+/* reference: src/spath_raytracer.c:118-132 */
+static void upload_random_buffer(spath_raytracer_context *c)
+{
+    raytracer_context *rctx = c->rctx;
+    const size_t n = (size_t)rctx->width * rctx->height;
+    if (c->rng_mode == RT_RNG_SPLITMIX) {
+        const size_t first = (size_t)rctx->tile_y0 * rctx->width;
+        for (size_t i = 0; i < n; i++) c->random_buffer[i] = splitmix32(c->rng_seed, (uint32_t)(first + i));
+    } else {
+        for (size_t i = 0; i < n; i++) c->random_buffer[i] = (unsigned int)rand();
+    }
+    rt_mem_upload(rctx->rcl->device, c->cl_random_buffer, c->random_buffer, n * sizeof(unsigned int));
+}
+
+/* f_buffer_to_byte_buffer_avg + blocking readback, reference: src/spath_raytracer.c:252-277 */
+void spath_raytracer_resolve(spath_raytracer_context *c)
+{
+    raytracer_context *rctx = c->rctx;
+    const unsigned int n = rctx->width * rctx->height;
+    rt_k_resolve_avg(rctx->rcl->device, rctx->cl_output_buffer, c->cl_path_output_buffer, n);
+    rt_mem_download(rctx->rcl->device, rctx->output_buffer, rctx->cl_output_buffer, (size_t)n * 4);
+}
+
+/* reference: src/spath_raytracer.c:404-436 */
+void spath_raytracer_prepass(spath_raytracer_context *c)
+{
+    raytracer_context *rctx = c->rctx;
+    rt_device *dev = rctx->rcl->device;
+    const unsigned int n = rctx->width * rctx->height;
+    const size_t n16 = (size_t)n * sizeof(vec4);
+
+    c->render_complete = false;
+    c->num_iterations = 2048 * 4;
+    c->rng_launch = 0;
+    if (c->rng_mode == RT_RNG_LIBC) srand((unsigned int)rt_time_ms());
+    c->start_time = rt_time_ms();
+
+    rt_mem_zero(dev, c->cl_path_output_buffer, n16);
+    raytracer_prepass(rctx);
+    kd_tree *kdt = rctx->stat_scene->kdt;
+    if (!kdt->root) {
+        fprintf(stderr, "ERROR: the split path tracer needs mesh triangles (the scene has none)\n");
+        exit(1);
+    }
+
+    c->current_iteration = 0;
+    rt_mem_zero(dev, c->cl_spath_progress_buffer, n16);
+    rt_mem_zero(dev, c->cl_spath_progress_b_buffer, n16);
+    _raytracer_gen_ray_buffer(rctx);
+
+    rt_spath_buffers b;
+    spath_raytracer_fill_buffers(c, &b);
+    rt_k_kd_intersect(dev, &kdt->view, b.ray_o, b.ray_d, b.hits, n);
+    rt_k_spath_init(dev, &kdt->view, &b, rctx->width, rctx->height, rctx->tile_y0, next_random_value(c));
+    upload_random_buffer(c);
+
+    /* the reference clears the ray buffer here (src/spath_raytracer.c:432-433),
+       discarding the first-bounce rays the init kernel has just written: the
+       first iteration traces null rays and finishes one sky-only sample */
+    rt_mem_zero(dev, rctx->cl_ray_buffer, n16);
+    rt_mem_zero(dev, rctx->cl_ray_dir_buffer, n16);
+    rt_device_sync(dev);
+}
+
+/* reference: src/spath_raytracer.c:355-402 */
+void spath_raytracer_render(spath_raytracer_context *c)
+{
+    raytracer_context *rctx = c->rctx;
+    rt_device *dev = rctx->rcl->device;
+    kd_tree *kdt = rctx->stat_scene->kdt;
+    const unsigned int n = rctx->width * rctx->height;
+    rt_spath_buffers b;
+    spath_raytracer_fill_buffers(c, &b);
+
+    c->current_iteration++;
+    if (c->current_iteration > c->num_iterations) {
+        /* the reference still steps the RNG buffer on this call (src/spath_raytracer.c:364-373) */
+        rt_k_xorshift(dev, b.random, n);
+        if (!c->render_complete) {
+            spath_raytracer_resolve(c);
+            if (!c->quiet) printf("Render took: %u ms\n", rt_time_ms() - c->start_time);
+        }
+        c->render_complete = true;
+        return;
+    }
+
+    const uint32_t rv = next_random_value(c);
+    if (c->separate_kernels) {
+        rt_k_xorshift(dev, b.random, n);
+        rt_k_kd_intersect(dev, &kdt->view, b.ray_o, b.ray_d, b.hits, n);
+        rt_k_spath_trace(dev, &kdt->view, &b, n, rv);
+    } else {
+        rt_k_spath_iteration(dev, &kdt->view, &b, n, rv);
+    }
+
+    if (c->resolve_interval && c->current_iteration % c->resolve_interval == 0) {
+        spath_raytracer_resolve(c);
+        if (!c->quiet)
+            printf("iteration %u  sample %u.%u/%u  elapsed %u ms\n", c->current_iteration, c->current_iteration / 4,
+                   c->current_iteration % 4, c->num_iterations / 4, rt_time_ms() - c->start_time);
+    }
+}
+
+void spath_raytracer_destroy(spath_raytracer_context *c)
+{
+    if (!c) return;
+    rt_device *dev = c->rctx->rcl->device;
+    rt_mem_free(dev, c->cl_path_output_buffer);
+    rt_mem_free(dev, c->cl_path_ray_origin_buffer);
+    rt_mem_free(dev, c->cl_path_ray_origin_dir_buffer);
+    rt_mem_free(dev, c->cl_path_collision_result_buffer);
+    rt_mem_free(dev, c->cl_path_origin_collision_result_buffer);
+    rt_mem_free(dev, c->cl_random_buffer);
+    rt_mem_free(dev, c->cl_spath_progress_buffer);
+    rt_mem_free(dev, c->cl_spath_progress_b_buffer);
+    free(c->random_buffer);
+    free(c);
+}

@@ -1,0 +1,188 @@
+// Device, stream, memory and event plumbing behind rt_hip.h.
+#include "rt_internal.hpp"
+
+#include <cstring>
+
+static const char *k_kernel_names[RT_K_COUNT] = {
+    "generate_rays", "kd_intersect", "spath_init", "spath_trace", "xorshift", "spath_iteration",
+    "resolve_avg", "cast_rays", "path_trace", "f_buffer_average", "f_to_byte"};
+
+extern "C" {
+
+int rt_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+rt_device *rt_device_open(int ordinal)
+{
+    int n = rt_device_count();
+    if (n <= 0) {
+        fprintf(stderr, "ERROR: no HIP device is visible; this library has no CPU fallback\n");
+        exit(1);
+    }
+    if (ordinal < 0 || ordinal >= n) {
+        fprintf(stderr, "ERROR: device ordinal %d out of range (%d visible)\n", ordinal, n);
+        exit(1);
+    }
+    rt_device *dev = new rt_device();
+    dev->ordinal = ordinal;
+    RT_HIP_CHECK(hipSetDevice(ordinal));
+    RT_HIP_CHECK(hipGetDeviceProperties(&dev->props, ordinal));
+    RT_HIP_CHECK(hipStreamCreateWithFlags(&dev->stream, hipStreamNonBlocking));
+    return dev;
+}
+
+void rt_device_close(rt_device *dev)
+{
+    if (!dev) return;
+    RT_HIP_CHECK(hipSetDevice(dev->ordinal));
+    RT_HIP_CHECK(hipStreamSynchronize(dev->stream));
+    for (int k = 0; k < RT_K_COUNT; k++) {
+        for (hipEvent_t e : dev->slots[k].start) (void)hipEventDestroy(e);
+        for (hipEvent_t e : dev->slots[k].stop) (void)hipEventDestroy(e);
+    }
+    for (hipEvent_t e : dev->free_events) (void)hipEventDestroy(e);
+    RT_HIP_CHECK(hipStreamDestroy(dev->stream));
+    delete dev;
+}
+
+void rt_device_get_props(rt_device *dev, rt_device_props *out)
+{
+    memset(out, 0, sizeof *out);
+    strncpy(out->name, dev->props.name, sizeof(out->name) - 1);
+    out->compute_units = dev->props.multiProcessorCount;
+    out->wave_size = dev->props.warpSize;
+    out->max_waves_per_cu = dev->props.maxThreadsPerMultiProcessor / (dev->props.warpSize ? dev->props.warpSize : 64);
+    out->global_mem_bytes = dev->props.totalGlobalMem;
+    out->lds_bytes_per_cu = dev->props.maxSharedMemoryPerMultiProcessor;
+}
+
+void rt_device_sync(rt_device *dev)
+{
+    RT_HIP_CHECK(hipStreamSynchronize(dev->stream));
+}
+
+void *rt_device_stream(rt_device *dev) { return (void *)dev->stream; }
+int rt_device_ordinal(rt_device *dev) { return dev->ordinal; }
+
+rt_mem rt_mem_alloc(rt_device *dev, size_t bytes)
+{
+    void *p = nullptr;
+    RT_HIP_CHECK(hipSetDevice(dev->ordinal));
+    RT_HIP_CHECK(hipMalloc(&p, bytes ? bytes : 16));
+    return p;
+}
+
+void rt_mem_free(rt_device *dev, rt_mem m)
+{
+    if (!m) return;
+    RT_HIP_CHECK(hipSetDevice(dev->ordinal));
+    RT_HIP_CHECK(hipStreamSynchronize(dev->stream));
+    RT_HIP_CHECK(hipFree(m));
+}
+
+void rt_mem_upload(rt_device *dev, rt_mem dst, const void *src, size_t bytes)
+{
+    if (!bytes) return;
+    RT_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, dev->stream));
+    RT_HIP_CHECK(hipStreamSynchronize(dev->stream));
+}
+
+void rt_mem_download(rt_device *dev, void *dst, rt_mem src, size_t bytes)
+{
+    if (!bytes) return;
+    RT_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, dev->stream));
+    RT_HIP_CHECK(hipStreamSynchronize(dev->stream));
+}
+
+void rt_mem_zero(rt_device *dev, rt_mem m, size_t bytes)
+{
+    if (!bytes) return;
+    RT_HIP_CHECK(hipMemsetAsync(m, 0, bytes, dev->stream));
+}
+
+void rt_mem_copy(rt_device *dev, rt_mem dst, rt_mem src, size_t bytes)
+{
+    if (!bytes) return;
+    RT_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, dev->stream));
+}
+
+void rt_timing_enable(rt_device *dev, int on) { dev->timing = on ? 1 : 0; }
+
+void rt_timing_reset(rt_device *dev)
+{
+    RT_HIP_CHECK(hipStreamSynchronize(dev->stream));
+    for (int k = 0; k < RT_K_COUNT; k++) {
+        rt_timing_fold(dev, k);
+        dev->slots[k].launches = 0;
+        dev->slots[k].total_ms = 0.0;
+    }
+}
+
+void rt_timing_get(rt_device *dev, int kernel_id, uint64_t *launches, double *total_ms)
+{
+    if (kernel_id < 0 || kernel_id >= RT_K_COUNT) { *launches = 0; *total_ms = 0; return; }
+    RT_HIP_CHECK(hipStreamSynchronize(dev->stream));
+    rt_timing_fold(dev, kernel_id);
+    *launches = dev->slots[kernel_id].launches;
+    *total_ms = dev->slots[kernel_id].total_ms;
+}
+
+const char *rt_kernel_name(int kernel_id)
+{
+    return (kernel_id >= 0 && kernel_id < RT_K_COUNT) ? k_kernel_names[kernel_id] : "?";
+}
+
+}  // extern "C"
+
+// Adds the finished event pairs of one kernel to its totals and recycles the
+// events.  The stream must have been synchronised.
+void rt_timing_fold(rt_device *dev, int kernel_id)
+{
+    rt_timing_slot &s = dev->slots[kernel_id];
+    for (size_t i = 0; i < s.start.size(); i++) {
+        float ms = 0.f;
+        RT_HIP_CHECK(hipEventElapsedTime(&ms, s.start[i], s.stop[i]));
+        s.total_ms += ms;
+        s.launches++;
+        dev->free_events.push_back(s.start[i]);
+        dev->free_events.push_back(s.stop[i]);
+    }
+    s.start.clear();
+    s.stop.clear();
+}
+
+static hipEvent_t take_event(rt_device *dev)
+{
+    if (!dev->free_events.empty()) {
+        hipEvent_t e = dev->free_events.back();
+        dev->free_events.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    RT_HIP_CHECK(hipEventCreate(&e));
+    return e;
+}
+
+rt_launch_timer::rt_launch_timer(rt_device *d, int kernel_id) : dev(d), id(kernel_id)
+{
+    if (!dev->timing) return;
+    if (dev->slots[id].start.size() >= 16384) {   // bound the number of live events
+        RT_HIP_CHECK(hipStreamSynchronize(dev->stream));
+        rt_timing_fold(dev, id);
+    }
+    e0 = take_event(dev);
+    e1 = take_event(dev);
+    RT_HIP_CHECK(hipEventRecord(e0, dev->stream));
+}
+
+rt_launch_timer::~rt_launch_timer()
+{
+    if (!e0) return;
+    RT_HIP_CHECK(hipEventRecord(e1, dev->stream));
+    dev->slots[id].start.push_back(e0);
+    dev->slots[id].stop.push_back(e1);
+}

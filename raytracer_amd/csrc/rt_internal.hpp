@@ -1,0 +1,49 @@
+// Shared between the device-management and kernel translation units.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "rt_hip.h"
+
+// Fatal-on-error convention of the host API: message, then exit(1).
+#define RT_HIP_CHECK(expr)                                                                        \
+    do {                                                                                          \
+        hipError_t rt_err_ = (expr);                                                              \
+        if (rt_err_ != hipSuccess) {                                                              \
+            fprintf(stderr, "ERROR: %s failed: %s (line %d, file %s)\n", #expr,                   \
+                    hipGetErrorString(rt_err_), __LINE__, __FILE__);                              \
+            fflush(stderr);                                                                       \
+            exit(1);                                                                              \
+        }                                                                                         \
+    } while (0)
+
+struct rt_timing_slot {
+    std::vector<hipEvent_t> start, stop;   // pairs still to be read back
+    uint64_t launches = 0;
+    double total_ms = 0.0;
+};
+
+struct rt_device {
+    int ordinal = 0;
+    hipStream_t stream = nullptr;
+    hipDeviceProp_t props;
+    int timing = 0;
+    rt_timing_slot slots[RT_K_COUNT];
+    std::vector<hipEvent_t> free_events;
+};
+
+// Brackets one launch with events when timing is on.
+struct rt_launch_timer {
+    rt_device *dev;
+    int id;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    rt_launch_timer(rt_device *d, int kernel_id);
+    ~rt_launch_timer();
+};
+
+void rt_timing_fold(rt_device *dev, int kernel_id);

@@ -1,0 +1,849 @@
+// HIP kernels of the path tracer for gfx950 (wave64) and their C-ABI launchers.
+//
+// Arithmetic contract: results must be bit-identical to a plain IEEE-754
+// single-precision evaluation in source order, so this file is built with
+// -ffp-contract=off and without any fast-math option; divisions and square
+// roots are the correctly rounded ones.  min/max follow OpenCL's
+// "y < x ? y : x" definitions, dot products are summed left to right.
+#include "rt_internal.hpp"
+
+#define RT_INF __builtin_huge_valf()
+#define RT_EPS 0.0000001f          /* EPSILON,   reference: src/kernels/util.cl:8 */
+#define RT_FAR 100000000.0f        /* FAR_PLANE, reference: src/kernels/util.cl:9 */
+#define RT_PI_F 3.14159274101257f  /* M_PI_F */
+
+namespace {
+
+struct f3 { float x, y, z; };
+
+__device__ __forceinline__ f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ f3 xyz(float4 v) { return mk3(v.x, v.y, v.z); }
+__device__ __forceinline__ f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ f3 cross3(f3 a, f3 b)
+{
+    return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ float cl_min(float a, float b) { return b < a ? b : a; }
+__device__ __forceinline__ float cl_max(float a, float b) { return a < b ? b : a; }
+__device__ __forceinline__ f3 normalize3(f3 a)
+{
+    float len = sqrtf(dot3(a, a));
+    return mk3(a.x / len, a.y / len, a.z / len);
+}
+__device__ __forceinline__ float4 mk4(f3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
+
+// sin and cos of an angle in [0, 2*pi]: three-constant Cody-Waite reduction to
+// [-pi/4, pi/4] and degree-7/8 minimax polynomials, plain float operations
+// only, so the host can reproduce the bits.
+__device__ __forceinline__ void sincos_2pi(float theta, float &s, float &c)
+{
+    int q = (int)(theta * 0.636619772367581343f + 0.5f);
+    float fq = (float)q;
+    float r = theta - fq * 1.5703125f;
+    r = r - fq * 4.837512969970703125e-4f;
+    r = r - fq * 7.54978995489188216e-8f;
+    float z = r * r;
+    float sp = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * r + r;
+    float cp = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z
+               - 0.5f * z + 1.0f;
+    switch (q & 3) {
+    case 0: s = sp; c = cp; break;
+    case 1: s = cp; c = -sp; break;
+    case 2: s = -sp; c = -cp; break;
+    default: s = -cp; c = sp; break;
+    }
+}
+
+// get_random, reference: src/kernels/util.cl:76-91
+__device__ __forceinline__ float get_random(uint32_t &s0, uint32_t &s1)
+{
+    s0 = 36969u * (s0 & 65535u) + (s0 >> 16);
+    s1 = 18000u * (s1 & 65535u) + (s1 >> 16);
+    uint32_t ires = (s0 << 16) + s1;
+    float f = __uint_as_float((ires & 0x007fffffu) | 0x40000000u);
+    return (f - 2.0f) / 2.0f;
+}
+
+// cosineSampleHemisphere, reference: src/kernels/path.cl:11-23
+__device__ __forceinline__ f3 cosine_hemisphere(float u1, float u2, f3 w)
+{
+    const float r = sqrtf(u1);
+    const float theta = 2.f * RT_PI_F * u2;
+    f3 axis = fabsf(w.x) > 0.1f ? mk3(0.0f, 1.0f, 0.0f) : mk3(1.0f, 0.0f, 0.0f);
+    f3 u = normalize3(cross3(axis, w));
+    f3 v = cross3(w, u);
+    float s, c;
+    sincos_2pi(theta, s, c);
+    f3 a = (u * c) * r;
+    f3 b = (v * s) * r;
+    f3 cc = w * sqrtf(1.0f - u1);
+    return normalize3((a + b) + cc);
+}
+
+// get_colour, reference: src/kernels/util.cl:57-74 (a NaN channel packs as 0)
+__device__ __forceinline__ uint32_t quant8(float f)
+{
+    f = cl_min(cl_max(f, 0.0f), 1.0f);
+    if (!(f == f)) f = 0.0f;
+    return (uint32_t)(f * 255);
+}
+__device__ __forceinline__ uint32_t get_colour(float x, float y, float z, float w)
+{
+    uint32_t out = 0;
+    out |= 0xff000000u & (quant8(w) << 24);
+    out |= 0x00ff0000u & (quant8(x) << 16);
+    out |= 0x0000ff00u & (quant8(y) << 8);
+    out |= 0x000000ffu & quant8(z);
+    return out;
+}
+
+// Moeller-Trumbore with back-face culling on precomputed edges,
+// reference: src/kernels/collision.cl:139-172
+__device__ __forceinline__ bool tri_hit_edges(f3 v0, f3 ab, f3 ac, f3 o, f3 d, float &t, float &u, float &v)
+{
+    f3 pvec = cross3(d, ac);
+    float det = dot3(ab, pvec);
+    if (det < RT_EPS) return false;
+    float inv = 1.f / det;
+    f3 tvec = o - v0;
+    u = dot3(tvec, pvec) * inv;
+    if (u < 0 || u > 1) return false;
+    f3 qvec = cross3(tvec, ab);
+    v = dot3(d, qvec) * inv;
+    if (v < 0 || u + v > 1) return false;
+    t = dot3(ac, qvec) * inv;
+    return true;
+}
+
+struct Hit { uint32_t tri; float t, u, v; };
+
+// ---------------------------------------------------------------------------
+// kd-tree traversal of one ray per lane.
+//
+// Follows the reference walk (src/kernels/kdtree.cl:188-318) decision for
+// decision: slab clip against the scene box, near/far choice by
+// "o<b || (o==b && d<=0)", near only when t_split > t_max or <= 0, far only
+// when t_split < t_min, otherwise push the far child; in a leaf the triangles
+// are tested in stored order and the walk stops at the first accepted hit that
+// lies before the leaf's exit distance.  The reference's restart-from-root
+// only ever fires on entry, so it is the loop's first iteration here.
+//
+// Stack entries are {far node, t_split}: an entry's t_max always equals the
+// t_split of the entry below it (scene_t_max for the bottom one), so it is not
+// stored.  The first LDS_DEPTH entries of each lane live in LDS, laid out
+// [level][lane] so that a wave's accesses never collide on a bank whatever the
+// lanes' depths are; deeper entries (rare) spill to a per-lane private array.
+// ---------------------------------------------------------------------------
+#define RT_MAX_STACK 64
+
+template <int LDS_DEPTH>
+__device__ __forceinline__ Hit kd_trace(const uint2 *__restrict__ nodes, const float4 *__restrict__ leaf_tris,
+                                        f3 o, f3 d, f3 smin, f3 smax, uint32_t root_is_leaf,
+                                        uint2 *__restrict__ lds_col)
+{
+    uint2 spill[RT_MAX_STACK - LDS_DEPTH];
+
+    // get_elem (kdtree.cl:67-75) adds the masked-out zeros, which turns -0 into +0
+    const float ocx = o.x + 0.0f, ocy = o.y + 0.0f, ocz = o.z + 0.0f;
+    const float dcx = d.x + 0.0f, dcy = d.y + 0.0f, dcz = d.z + 0.0f;
+
+    float t_hit = RT_INF, hu = 0.f, hv = 0.f;
+    uint32_t tri_indx = 0;
+
+    // getTBoundingBox, reference: src/kernels/collision.cl:71-86
+    float scene_t_min = 0.f, scene_t_max = RT_INF;
+    {
+        f3 inv = mk3(1 / d.x, 1 / d.y, 1 / d.z);
+        f3 t0 = (smin - o) * inv, t1 = (smax - o) * inv;
+        f3 sm = mk3(cl_min(t0.x, t1.x), cl_min(t0.y, t1.y), cl_min(t0.z, t1.z));
+        f3 bg = mk3(cl_max(t0.x, t1.x), cl_max(t0.y, t1.y), cl_max(t0.z, t1.z));
+        scene_t_min = cl_max(scene_t_min, cl_max(sm.x, cl_max(sm.y, sm.z)));
+        scene_t_max = cl_min(scene_t_max, cl_min(bg.x, cl_min(bg.y, bg.z)));
+        if (!(scene_t_min < scene_t_max)) scene_t_max = -RT_INF;
+    }
+    float t_min = scene_t_min, t_max = scene_t_min;
+    uint32_t sp = 0;
+    bool early = false;
+
+    while (t_max < scene_t_max && !early) {
+        uint32_t cur;
+        if (sp == 0) {
+            cur = 0; t_min = t_max; t_max = scene_t_max;
+        } else {
+            sp--;
+            uint2 e = (sp < LDS_DEPTH) ? lds_col[sp * 64] : spill[sp - LDS_DEPTH];
+            cur = e.x;
+            t_min = __uint_as_float(e.y);
+            if (sp == 0) t_max = scene_t_max;
+            else {
+                uint2 below = (sp - 1 < LDS_DEPTH) ? lds_col[(sp - 1) * 64] : spill[sp - 1 - LDS_DEPTH];
+                t_max = __uint_as_float(below.y);
+            }
+        }
+
+        uint2 node = nodes[cur];
+        while ((node.y & 3u) != 3u) {
+            const uint32_t k = node.y & 3u;
+            const float b = __uint_as_float(node.x);
+            const float ok = (k == 0) ? ocx : ((k == 1) ? ocy : ocz);
+            const float dk = (k == 0) ? dcx : ((k == 1) ? dcy : dcz);
+            const float t_split = (b - ok) / dk;
+            const bool left_close = (ok < b) || (ok == b && dk <= 0);
+            const uint32_t left = cur + 1, right = node.y >> 2;
+            const uint32_t first = left_close ? left : right;
+            const uint32_t second = left_close ? right : left;
+            const bool c1 = (t_split > t_max || t_split <= 0);
+            const bool c2 = (t_split < t_min);
+            cur = (c1 || !c2) ? first : second;
+            if (!c1 && !c2) {
+                uint2 e = make_uint2(second, __float_as_uint(t_split));
+                if (sp < LDS_DEPTH) lds_col[sp * 64] = e;
+                else if (sp < RT_MAX_STACK) spill[sp - LDS_DEPTH] = e;
+                sp++;
+                t_max = t_split;
+            }
+            node = nodes[cur];
+        }
+
+        const uint32_t count = node.y >> 2;
+        const float4 *tp = leaf_tris + 3 * (size_t)node.x;
+        for (uint32_t i = 0; i < count; i++, tp += 3) {
+            const float4 a = tp[0], e1 = tp[1], e2 = tp[2];
+            float t, u, v;
+            if (tri_hit_edges(xyz(a), xyz(e1), xyz(e2), o, d, t, u, v)) {
+                if (t <= 0) continue;
+                if (t < t_hit) {
+                    t_hit = t; hu = u; hv = v; tri_indx = __float_as_uint(a.w);
+                    if (t_hit < t_max) { early = true; break; }
+                }
+            }
+        }
+        if (root_is_leaf) break;
+    }
+
+    Hit h;
+    if (!isinf(t_hit)) { h.tri = tri_indx; h.t = t_hit; h.u = hu; h.v = hv; }
+    else { h.tri = 0; h.t = 0.f; h.u = 0.f; h.v = 0.f; }
+    return h;
+}
+
+// Surface data of a hit: interpolated (unnormalised) normal, material colour
+// and reflectivity.  reference: src/kernels/path.cl:160-171
+struct Surface { f3 normal, colour; float refl; };
+
+__device__ __forceinline__ Surface surface_at(const float4 *__restrict__ tri_shade, const Hit &h)
+{
+    const float4 *rec = tri_shade + 4 * (size_t)(h.tri / 3u);
+    const float4 a = rec[0], b = rec[1], c = rec[2], m = rec[3];
+    Surface s;
+    s.normal = (xyz(a) * (1 - h.u - h.v) + xyz(b) * h.u) + xyz(c) * h.v;
+    s.colour = mk3(a.w, b.w, c.w);
+    s.refl = m.x;
+    return s;
+}
+
+// One step of segmented_path_trace for one pixel (src/kernels/path.cl:142-256,
+// non-Windows branch: the finished sample is added to out_tex as .zyx).
+__device__ __forceinline__ void spath_step(const float4 *__restrict__ tri_shade, Hit res, f3 o, f3 d,
+                                           uint32_t rnd, uint32_t random_value, uint32_t i,
+                                           float4 *__restrict__ out_tex, const float4 *__restrict__ origin_o,
+                                           const float4 *__restrict__ origin_d, const Hit *__restrict__ source_hits,
+                                           float4 &pa, float4 &pb, f3 &new_o, f3 &new_d)
+{
+    const f3 sky = mk3((float)0.16, (float)0.2, (float)0.2);
+    uint32_t sample_num = __float_as_uint(pa.w), bounce_num = __float_as_uint(pb.w);
+    f3 mask = xyz(pa), accum = xyz(pb);
+
+    Surface sf = surface_at(tri_shade, res);
+    f3 pos = o + d * res.t;
+
+    uint32_t seed1 = rnd * random_value, seed2 = rnd;
+    float rand1 = get_random(seed1, seed2);
+    float rand2 = get_random(seed2, seed1);
+
+    f3 sdir = cosine_hemisphere(rand1, rand2, sf.normal);
+    f3 sorig = pos + sf.normal * 0.0001f;
+
+    if (res.t == 0) {
+        bounce_num = 4;
+        accum = accum + mask * sky;
+    } else {
+        float e = (sf.refl == 1.f) ? 1.0f : 0.0f;
+        accum = accum + (mask * e) * 2.f;
+        mask = mask * sf.colour;
+        mask = mask * dot3(sdir, sf.normal);
+    }
+    bounce_num++;
+
+    if (bounce_num >= 4) {
+        bounce_num = 0;
+        sample_num++;
+        float4 ot = out_tex[i];
+        ot.x += accum.z; ot.y += accum.y; ot.z += accum.x; ot.w += 1.0f;
+
+        res = source_hits[i];
+        o = xyz(origin_o[i]); d = xyz(origin_d[i]);
+        mask = mk3(1.0f, 1.0f, 1.0f);
+        accum = mk3(0.f, 0.f, 0.f);
+        if (res.t == 0) { ot.x += sky.x; ot.y += sky.y; ot.z += sky.z; ot.w += 0.0f; }
+        out_tex[i] = ot;
+
+        sf = surface_at(tri_shade, res);
+        pos = o + d * res.t;
+        mask = mask * sf.colour;
+        if (sf.refl == 1.f) accum = accum + mask * 2.f;
+        sdir = cosine_hemisphere(rand1, rand2, sf.normal);
+        sorig = pos + sf.normal * 0.0001f;
+    }
+    new_o = sorig; new_d = sdir;
+    pa = mk4(mask, __uint_as_float(sample_num));
+    pb = mk4(accum, __uint_as_float(bounce_num));
+}
+
+// ---------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------
+constexpr int kTraverseLdsDepth = 16;
+
+// generate_rays, reference: src/kernels/ray.cl:109-133.  The reference's 0.5
+// literals are doubles, so the camera-plane coordinates go through double.
+__global__ void k_generate_rays(float4 *__restrict__ ray_o, float4 *__restrict__ ray_d, uint32_t w, uint32_t h,
+                                uint32_t y0, uint32_t full_h, float tan_half)
+{
+    uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= w * h) return;
+    uint32_t x = id % w, y = id / w + y0;
+    float aspect = w / (float)full_h;
+    float cam_x = (float)((2 * (((float)x + 0.5) / w) - 1) * tan_half * aspect);
+    float cam_y = (float)((1 - 2 * (((float)y + 0.5) / full_h)) * tan_half);
+    f3 dir = normalize3(mk3(cam_x, cam_y, -1.0f));
+    ray_o[id] = make_float4(0.f, 0.f, 0.f, 0.f);
+    ray_d[id] = mk4(dir, 0.f);
+}
+
+__global__ __launch_bounds__(64) void k_kd_intersect(const uint2 *__restrict__ nodes,
+                                                     const float4 *__restrict__ leaf_tris,
+                                                     const float4 *__restrict__ ray_o,
+                                                     const float4 *__restrict__ ray_d, Hit *__restrict__ hits,
+                                                     uint32_t n, f3 smin, f3 smax, uint32_t root_is_leaf)
+{
+    __shared__ uint2 stack[kTraverseLdsDepth * 64];
+    uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    Hit h = kd_trace<kTraverseLdsDepth>(nodes, leaf_tris, xyz(ray_o[i]), xyz(ray_d[i]), smin, smax, root_is_leaf,
+                                        stack + threadIdx.x);
+    hits[i] = h;
+}
+
+// segmented_path_trace_init, reference: src/kernels/path.cl:36-113.  The
+// reference leaves sample_num / bounce_num of the record it stores
+// uninitialised; they are written as 0 here.
+__global__ void k_spath_init(const float4 *__restrict__ tri_shade, float4 *__restrict__ out_tex,
+                             float4 *__restrict__ ray_o, float4 *__restrict__ ray_d,
+                             float4 *__restrict__ origin_o, float4 *__restrict__ origin_d,
+                             const Hit *__restrict__ hits, Hit *__restrict__ source_hits,
+                             float4 *__restrict__ prog_a, float4 *__restrict__ prog_b, uint32_t w, uint32_t h,
+                             uint32_t y0, uint32_t random_value)
+{
+    uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= w * h) return;
+    uint32_t x = id % w, y = id / w + y0;
+
+    Hit res = hits[id];
+    float4 ro = ray_o[id], rd = ray_d[id];
+    origin_o[id] = ro; origin_d[id] = rd;
+    source_hits[id] = res;
+
+    if (res.t == 0) {
+        float4 ot = out_tex[id];
+        ot.x += (float)0.16 * 2; ot.y += (float)0.2 * 2; ot.z += (float)0.2 * 2; ot.w += 0.0f;
+        out_tex[id] = ot;
+    }
+    uint32_t seed1 = random_value * x, seed2 = random_value * y;
+    for (int i = 0; i < 7; i++) get_random(seed1, seed2);
+    float rand1 = get_random(seed1, seed2);
+    float rand2 = get_random(seed1, seed2);
+
+    Surface sf = surface_at(tri_shade, res);
+    f3 pos = xyz(ro) + xyz(rd) * res.t;
+    f3 mask = mk3(1.0f, 1.0f, 1.0f) * sf.colour;
+    f3 dir = cosine_hemisphere(rand1, rand2, sf.normal);
+    f3 so = pos + sf.normal * 0.0001f;
+    ray_o[id] = mk4(so, 0.f);
+    ray_d[id] = mk4(dir, 0.f);
+    prog_a[id] = mk4(mask, __uint_as_float(0u));
+    prog_b[id] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0u));
+}
+
+// segmented_path_trace, reference: src/kernels/path.cl:115-258
+__global__ void k_spath_trace(const float4 *__restrict__ tri_shade, float4 *__restrict__ out_tex,
+                              float4 *__restrict__ ray_o, float4 *__restrict__ ray_d,
+                              const float4 *__restrict__ origin_o, const float4 *__restrict__ origin_d,
+                              const Hit *__restrict__ hits, const Hit *__restrict__ source_hits,
+                              float4 *__restrict__ prog_a, float4 *__restrict__ prog_b,
+                              const uint32_t *__restrict__ random, uint32_t n, uint32_t random_value)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 pa = prog_a[i], pb = prog_b[i];
+    if (__float_as_uint(pa.w) == 2048u) {       // reference: path.cl:145-152
+        ray_o[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        ray_d[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    f3 no, nd;
+    spath_step(tri_shade, hits[i], xyz(ray_o[i]), xyz(ray_d[i]), random[i], random_value, i, out_tex, origin_o,
+               origin_d, source_hits, pa, pb, no, nd);
+    ray_o[i] = mk4(no, 0.f);
+    ray_d[i] = mk4(nd, 0.f);
+    prog_a[i] = pa;
+    prog_b[i] = pb;
+}
+
+// xorshift_batch, reference: src/kernels/path.cl:421-426
+__global__ void k_xorshift(uint32_t *__restrict__ data, uint32_t n)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t d = data[i];
+    data[i] = ((d << 1) | (d >> 31)) + 1;
+}
+
+// One render iteration per pixel in a single launch: RNG step, traversal of
+// the pixel's current ray, shading / path regeneration.  Same per-pixel
+// sequence as the three reference launches (src/spath_raytracer.c:364-385);
+// the hit record is also stored so the buffers end up as those launches
+// leave them.
+__global__ __launch_bounds__(64) void k_spath_iteration(
+    const uint2 *__restrict__ nodes, const float4 *__restrict__ leaf_tris, const float4 *__restrict__ tri_shade,
+    float4 *__restrict__ out_tex, float4 *__restrict__ ray_o, float4 *__restrict__ ray_d,
+    const float4 *__restrict__ origin_o, const float4 *__restrict__ origin_d, Hit *__restrict__ hits,
+    const Hit *__restrict__ source_hits, float4 *__restrict__ prog_a, float4 *__restrict__ prog_b,
+    uint32_t *__restrict__ random, uint32_t n, uint32_t random_value, f3 smin, f3 smax, uint32_t root_is_leaf)
+{
+    __shared__ uint2 stack[kTraverseLdsDepth * 64];
+    uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+
+    uint32_t rnd = random[i];
+    rnd = ((rnd << 1) | (rnd >> 31)) + 1;
+    random[i] = rnd;
+
+    f3 o = xyz(ray_o[i]), d = xyz(ray_d[i]);
+    Hit h = kd_trace<kTraverseLdsDepth>(nodes, leaf_tris, o, d, smin, smax, root_is_leaf, stack + threadIdx.x);
+    hits[i] = h;
+
+    float4 pa = prog_a[i], pb = prog_b[i];
+    if (__float_as_uint(pa.w) == 2048u) {
+        ray_o[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        ray_d[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    f3 no, nd;
+    spath_step(tri_shade, h, o, d, rnd, random_value, i, out_tex, origin_o, origin_d, source_hits, pa, pb, no, nd);
+    ray_o[i] = mk4(no, 0.f);
+    ray_d[i] = mk4(nd, 0.f);
+    prog_a[i] = pa;
+    prog_b[i] = pb;
+}
+
+// f_buffer_to_byte_buffer_avg, reference: src/kernels/path.cl:428-444
+__global__ void k_resolve_avg(uint32_t *__restrict__ out, const float4 *__restrict__ out_tex, uint32_t n)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 d = out_tex[i];
+    out[i] = (d.w == 0) ? get_colour(0.f, 0.f, 0.f, 0.f) : get_colour(d.x / d.w, d.y / d.w, d.z / d.w, d.w / d.w);
+}
+
+// f_buffer_to_byte_buffer, reference: src/kernels/path.cl:447-458
+__global__ void k_f_to_byte(uint32_t *__restrict__ out, const float4 *__restrict__ tex, uint32_t n)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 d = tex[i];
+    out[i] = get_colour(d.x, d.y, d.z, d.w);
+}
+
+// f_buffer_average, reference: src/kernels/path.cl:394-419
+__global__ void k_f_buffer_average(float4 *__restrict__ out_tex, const float4 *__restrict__ fresh, uint32_t n,
+                                   uint32_t sample)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 o = out_tex[i], f = fresh[i];
+    float s = (float)sample, sm1 = (float)sample - 1.f;
+    o.x = ((o.x - 0.5f) * sm1 + (f.x - 0.5f)) / s;
+    o.y = ((o.y - 0.5f) * sm1 + (f.y - 0.5f)) / s;
+    o.z = ((o.z - 0.5f) * sm1 + (f.z - 0.5f)) / s;
+    o.w = ((o.w - 0.5f) * sm1 + (f.w - 0.5f)) / s;
+    out_tex[i] = o;
+}
+
+// ---------------------------------------------------------------------------
+// brute-force scene intersection for the SS and PATH integrators
+// (reference: src/kernels/collision.cl:106-121,179-285,382-468)
+// ---------------------------------------------------------------------------
+struct SceneDev {
+    const int4 *idx4;
+    const float4 *verts4, *normals4;
+    const float4 *meshes;      // 8 float4 per mesh record
+    const float4 *materials;   // 2 float4 per material
+    const float4 *spheres;     // 2 float4 per sphere
+    const float4 *planes;      // 3 float4 per plane
+    uint32_t num_meshes, num_spheres, num_planes;
+};
+
+struct Coll { bool did_hit; f3 normal, point; float dist; f3 colour; float refl; };
+
+__device__ __forceinline__ void load_mat(const SceneDev &s, int mi, f3 &colour, float &refl)
+{
+    colour = xyz(s.materials[2 * (size_t)mi]);
+    refl = s.materials[2 * (size_t)mi + 1].x;
+}
+
+__device__ __forceinline__ bool slab_hit(f3 vmin, f3 vmax, f3 o, f3 d)
+{
+    f3 a = mk3((vmin.x - o.x) / d.x, (vmin.y - o.y) / d.y, (vmin.z - o.z) / d.z);
+    f3 b = mk3((vmax.x - o.x) / d.x, (vmax.y - o.y) / d.y, (vmax.z - o.z) / d.z);
+    f3 rmin = mk3(cl_min(a.x, b.x), cl_min(a.y, b.y), cl_min(a.z, b.z));
+    f3 rmax = mk3(cl_max(a.x, b.x), cl_max(a.y, b.y), cl_max(a.z, b.z));
+    float mm = cl_min(cl_min(rmax.x, rmax.y), rmax.z);
+    float xm = cl_max(cl_max(rmin.x, rmin.y), rmin.z);
+    f3 minmax = mk3(mm, mm, mm), maxmin = mk3(xm, xm, xm);
+    if (dot3(minmax, minmax) >= dot3(maxmin, maxmin)) return dot3(maxmin, maxmin) > 0.001f;
+    return false;
+}
+
+__device__ bool collide_primitives(const SceneDev &s, f3 o, f3 d, Coll &res)
+{
+    float dist = RT_FAR;
+    res.did_hit = false; res.dist = RT_FAR;
+    for (uint32_t i = 0; i < s.num_spheres; i++) {
+        float4 p = s.spheres[2 * i], q = s.spheres[2 * i + 1];
+        f3 c = xyz(p);
+        float radius = q.x;
+        int mi = __float_as_int(q.y);
+        f3 L = c - o;
+        float b = dot3(d, L);
+        float cc = dot3(L, L) - (radius * radius);
+        float disc = b * b - cc;
+        if (disc < 0.0f) continue;
+        float t = b - sqrtf(disc);
+        if (t < 0.0f) { t = b + sqrtf(disc); if (t < 0.0f) continue; }
+        if (t < dist) {
+            dist = t; res.did_hit = true; res.dist = dist;
+            res.point = d * dist + o;
+            res.normal = normalize3(res.point - c);
+            load_mat(s, mi, res.colour, res.refl);
+        }
+    }
+    for (uint32_t i = 0; i < s.num_planes; i++) {
+        f3 pp = xyz(s.planes[3 * i]), pn = xyz(s.planes[3 * i + 1]);
+        int mi = __float_as_int(s.planes[3 * i + 2].x);
+        float denom = dot3(d, pn);
+        if (denom < RT_EPS) {
+            f3 l = pp - o;
+            float t = dot3(l, pn) / denom;
+            if (t >= 0 && t < dist) {
+                dist = t; res.did_hit = true; res.dist = dist;
+                res.point = d * dist + o;
+                res.normal = pn;
+                load_mat(s, mi, res.colour, res.refl);
+            }
+        }
+    }
+    return dist != RT_FAR;
+}
+
+__device__ bool collide_meshes(const SceneDev &s, f3 o, f3 d, Coll &res)
+{
+    float dist = RT_FAR;
+    res.did_hit = false; res.dist = RT_FAR;
+    for (uint32_t m = 0; m < s.num_meshes; m++) {
+        const float4 *mp = s.meshes + 8 * (size_t)m;
+        f3 bmax = xyz(mp[4]), bmin = xyz(mp[5]);
+        float4 tail = mp[6];
+        int index_offset = __float_as_int(tail.x), num_indices = __float_as_int(tail.y), mi = __float_as_int(tail.z);
+        if (!slab_hit(bmin, bmax, o, d)) continue;
+        float min_t = RT_FAR;
+        f3 normal = mk3(0.f, 0.f, 0.f);
+        for (int i = 0; i < num_indices / 3; i++) {
+            int4 i0 = s.idx4[i * 3 + index_offset], i1 = s.idx4[i * 3 + index_offset + 1],
+                 i2 = s.idx4[i * 3 + index_offset + 2];
+            f3 a = xyz(s.verts4[i0.x]), b = xyz(s.verts4[i1.x]), c = xyz(s.verts4[i2.x]);
+            float t = 0.f, u = 0.f, v = 0.f;
+            if (tri_hit_edges(a, b - a, c - a, o, d, t, u, v) && t < min_t && t > 0) {
+                min_t = t;
+                normal = (xyz(s.normals4[i0.y]) * (1 - u - v) + xyz(s.normals4[i1.y]) * u) + xyz(s.normals4[i2.y]) * v;
+            }
+        }
+        if (min_t != RT_FAR && min_t < dist) {
+            dist = min_t;
+            res.dist = dist; res.normal = normal;
+            res.point = d * dist + o;
+            load_mat(s, mi, res.colour, res.refl);
+            res.did_hit = true;
+        }
+    }
+    return res.did_hit;
+}
+
+__device__ bool collide_all(const SceneDev &s, f3 o, f3 d, Coll &res)
+{
+    float dist = RT_FAR;
+    if (collide_primitives(s, o, d, res)) dist = res.dist;
+    Coll m;
+    if (collide_meshes(s, o, d, m))
+        if (m.dist < dist) res = m;
+    return res.did_hit;
+}
+
+// shade, reference: src/kernels/ray.cl:2-14
+__device__ float4 ss_shade(const SceneDev &s, const Coll &c)
+{
+    f3 l = normalize3(mk3(1.f, 2.f, 0.f) - c.point);
+    f3 ro = c.point + l * 0.00001f;
+    Coll tmp;
+    float vis = collide_all(s, ro, l, tmp) ? 0.0f : 1.0f;
+    return make_float4(vis * c.colour.x, vis * c.colour.y, vis * c.colour.z, vis * 1.0f);
+}
+
+__device__ __forceinline__ f3 reflect3(f3 i, f3 n) { return i - n * (2.f * dot3(i, n)); }
+__device__ __forceinline__ float4 mix4(float4 a, float4 b, float t)
+{
+    return make_float4(a.x + (b.x - a.x) * t, a.y + (b.y - a.y) * t, a.z + (b.z - a.z) * t, a.w + (b.w - a.w) * t);
+}
+
+// cast_ray_test, reference: src/kernels/ray.cl:17-105 (non-Windows: packed as .zyxw)
+__global__ void k_cast_rays(SceneDev s, uint32_t *__restrict__ out, const float4 *__restrict__ ray_o,
+                            const float4 *__restrict__ ray_d, uint32_t n)
+{
+    uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n) return;
+    const float4 sky = make_float4((float)0.84, (float)0.87, (float)0.93, 0.f);
+    f3 o = xyz(ray_o[id]), d = xyz(ray_d[id]);
+    Coll result;
+    if (!collide_all(s, o, d, result)) { out[id] = get_colour(sky.x, sky.y, sky.z, sky.w); return; }
+    float4 colour = ss_shade(s, result);
+
+    f3 rdir0, rdir1;
+    Coll r0, r1;
+    float4 c0 = sky, c1 = sky;
+    int early = 2;
+    {
+        f3 ro = result.point + result.normal * 0.0001f;
+        rdir0 = reflect3(d, result.normal);
+        if (collide_all(s, ro, rdir0, r0)) {
+            c0 = ss_shade(s, r0);
+            f3 ro1 = r0.point + r0.normal * 0.0001f;
+            rdir1 = reflect3(rdir0, r0.normal);
+            if (collide_all(s, ro1, rdir1, r1)) c1 = ss_shade(s, r1);
+            else { c1 = sky; early = 1; }
+        } else { c0 = sky; early = 0; }
+    }
+    if (early == 2) c1 = mix4(c1, sky, r1.refl);
+    if (early >= 1) c0 = mix4(c0, c1, r0.refl);
+    colour = mix4(colour, c0, result.refl);
+    out[id] = get_colour(colour.z, colour.y, colour.x, colour.w);
+}
+
+// path_trace, reference: src/kernels/path.cl:260-366 (non-Windows: stored as .zyx)
+__global__ void k_path_trace(SceneDev s, float4 *__restrict__ out_tex, const float4 *__restrict__ ray_d, uint32_t w,
+                             uint32_t h, f3 cam, uint32_t magic)
+{
+    uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= w || y >= h) return;
+    uint32_t off = x + y * w;
+    const f3 sky = mk3((float)0.16, (float)0.2, (float)0.2);
+    f3 d = xyz(ray_d[off]);
+    f3 o = cam;
+
+    float f = (float)magic * RT_PI_F + (float)(int)x;
+    uint32_t seed1 = __float_as_uint(f) + (uint32_t)(int)(sinf((float)(int)x) * 7.1f);
+    f = (float)magic * RT_PI_F + (float)(int)y;
+    uint32_t seed2 = y + (uint32_t)(int)(sinf((float)__float_as_uint(f)) * 7 * 3.f);
+
+    Coll first;
+    if (!collide_all(s, o, d, first)) { out_tex[off] = make_float4(sky.x, sky.y, sky.z, 0.f); return; }
+    f3 fin = mk3(0.f, 0.f, 0.f);
+    for (int i = 0; i < 4; i++) {
+        f3 accum = mk3(0.f, 0.f, 0.f), mask = mk3(1.f, 1.f, 1.f);
+        float rand1 = get_random(seed1, seed2);
+        float rand2 = get_random(seed1, seed2);
+        f3 sdir = cosine_hemisphere(rand1, rand2, first.normal);
+        f3 so = first.point + first.normal * 0.0001f;
+        mask = mask * first.colour;
+        for (int b = 0; b < 4; b++) {
+            Coll r;
+            if (!collide_all(s, so, sdir, r)) { accum = accum + mask * sky; break; }
+            rand1 = get_random(seed1, seed2);
+            rand2 = get_random(seed1, seed2);
+            sdir = cosine_hemisphere(rand1, rand2, r.normal);
+            so = r.point + r.normal * 0.0001f;
+            float e = (r.refl == 1.f) ? 1.0f : 0.0f;
+            accum = accum + (mask * e) * 2.f;
+            mask = mask * r.colour;
+            mask = mask * dot3(sdir, r.normal);
+        }
+        accum = mk3(cl_min(cl_max(accum.x, 0.f), 1.f), cl_min(cl_max(accum.y, 0.f), 1.f),
+                    cl_min(cl_max(accum.z, 0.f), 1.f));
+        fin = fin + accum * (1.f / 4);
+    }
+    out_tex[off] = make_float4(fin.z, fin.y, fin.x, 1.f);
+}
+
+inline unsigned blocks_for(uint32_t n, unsigned bs) { return (n + bs - 1) / bs; }
+inline f3 host3(const float *p) { f3 r; r.x = p[0]; r.y = p[1]; r.z = p[2]; return r; }
+
+SceneDev make_scene_dev(const rt_scene_view *sc)
+{
+    SceneDev s;
+    s.idx4 = (const int4 *)sc->idx4;
+    s.verts4 = (const float4 *)sc->verts4;
+    s.normals4 = (const float4 *)sc->normals4;
+    s.meshes = (const float4 *)sc->meshes;
+    s.materials = (const float4 *)sc->materials;
+    s.spheres = (const float4 *)sc->spheres;
+    s.planes = (const float4 *)sc->planes;
+    s.num_meshes = sc->num_meshes; s.num_spheres = sc->num_spheres; s.num_planes = sc->num_planes;
+    return s;
+}
+
+void check_kd(const rt_kd_view *kd, const char *who)
+{
+    if (!kd || !kd->nodes || !kd->leaf_tris || !kd->tri_shade || kd->num_nodes == 0) {
+        fprintf(stderr, "ERROR: %s: the flattened kd-tree has not been uploaded (no mesh triangles in the scene?)\n", who);
+        exit(1);
+    }
+}
+
+}  // namespace
+
+#define RT_AFTER_LAUNCH() RT_HIP_CHECK(hipGetLastError())
+
+extern "C" {
+
+void rt_k_generate_rays(rt_device *dev, rt_mem ray_o, rt_mem ray_d, uint32_t w, uint32_t h, uint32_t y0,
+                        uint32_t full_h, float tan_half_fov)
+{
+    uint32_t n = w * h;
+    if (!n) return;
+    rt_launch_timer tm(dev, RT_K_GENERATE_RAYS);
+    hipLaunchKernelGGL(k_generate_rays, dim3(blocks_for(n, 256)), dim3(256), 0, dev->stream, (float4 *)ray_o,
+                       (float4 *)ray_d, w, h, y0, full_h, tan_half_fov);
+    RT_AFTER_LAUNCH();
+}
+
+void rt_k_kd_intersect(rt_device *dev, const rt_kd_view *kd, rt_mem ray_o, rt_mem ray_d, rt_mem hits, uint32_t n)
+{
+    if (!n) return;
+    check_kd(kd, "rt_k_kd_intersect");
+    rt_launch_timer tm(dev, RT_K_KD_INTERSECT);
+    hipLaunchKernelGGL(k_kd_intersect, dim3(blocks_for(n, 64)), dim3(64), 0, dev->stream, (const uint2 *)kd->nodes,
+                       (const float4 *)kd->leaf_tris, (const float4 *)ray_o, (const float4 *)ray_d, (Hit *)hits, n,
+                       host3(kd->scene_min), host3(kd->scene_max), kd->root_is_leaf);
+    RT_AFTER_LAUNCH();
+}
+
+void rt_k_spath_init(rt_device *dev, const rt_kd_view *kd, const rt_spath_buffers *b, uint32_t w, uint32_t h,
+                     uint32_t y0, uint32_t random_value)
+{
+    if (!(w * h)) return;
+    check_kd(kd, "rt_k_spath_init");
+    rt_launch_timer tm(dev, RT_K_SPATH_INIT);
+    hipLaunchKernelGGL(k_spath_init, dim3(blocks_for(w * h, 256)), dim3(256), 0, dev->stream,
+                       (const float4 *)kd->tri_shade, (float4 *)b->out_tex, (float4 *)b->ray_o, (float4 *)b->ray_d,
+                       (float4 *)b->origin_o, (float4 *)b->origin_d, (const Hit *)b->hits, (Hit *)b->source_hits,
+                       (float4 *)b->prog_a, (float4 *)b->prog_b, w, h, y0, random_value);
+    RT_AFTER_LAUNCH();
+}
+
+void rt_k_spath_trace(rt_device *dev, const rt_kd_view *kd, const rt_spath_buffers *b, uint32_t n, uint32_t random_value)
+{
+    if (!n) return;
+    check_kd(kd, "rt_k_spath_trace");
+    rt_launch_timer tm(dev, RT_K_SPATH_TRACE);
+    hipLaunchKernelGGL(k_spath_trace, dim3(blocks_for(n, 256)), dim3(256), 0, dev->stream,
+                       (const float4 *)kd->tri_shade, (float4 *)b->out_tex, (float4 *)b->ray_o, (float4 *)b->ray_d,
+                       (const float4 *)b->origin_o, (const float4 *)b->origin_d, (const Hit *)b->hits,
+                       (const Hit *)b->source_hits, (float4 *)b->prog_a, (float4 *)b->prog_b,
+                       (const uint32_t *)b->random, n, random_value);
+    RT_AFTER_LAUNCH();
+}
+
+void rt_k_xorshift(rt_device *dev, rt_mem random, uint32_t n)
+{
+    if (!n) return;
+    rt_launch_timer tm(dev, RT_K_XORSHIFT);
+    hipLaunchKernelGGL(k_xorshift, dim3(blocks_for(n, 256)), dim3(256), 0, dev->stream, (uint32_t *)random, n);
+    RT_AFTER_LAUNCH();
+}
+
+void rt_k_spath_iteration(rt_device *dev, const rt_kd_view *kd, const rt_spath_buffers *b, uint32_t n,
+                          uint32_t random_value)
+{
+    if (!n) return;
+    check_kd(kd, "rt_k_spath_iteration");
+    rt_launch_timer tm(dev, RT_K_SPATH_ITERATION);
+    hipLaunchKernelGGL(k_spath_iteration, dim3(blocks_for(n, 64)), dim3(64), 0, dev->stream,
+                       (const uint2 *)kd->nodes, (const float4 *)kd->leaf_tris, (const float4 *)kd->tri_shade,
+                       (float4 *)b->out_tex, (float4 *)b->ray_o, (float4 *)b->ray_d, (const float4 *)b->origin_o,
+                       (const float4 *)b->origin_d, (Hit *)b->hits, (const Hit *)b->source_hits, (float4 *)b->prog_a,
+                       (float4 *)b->prog_b, (uint32_t *)b->random, n, random_value, host3(kd->scene_min),
+                       host3(kd->scene_max), kd->root_is_leaf);
+    RT_AFTER_LAUNCH();
+}
+
+void rt_k_resolve_avg(rt_device *dev, rt_mem out_u32, rt_mem out_tex, uint32_t n)
+{
+    if (!n) return;
+    rt_launch_timer tm(dev, RT_K_RESOLVE_AVG);
+    hipLaunchKernelGGL(k_resolve_avg, dim3(blocks_for(n, 256)), dim3(256), 0, dev->stream, (uint32_t *)out_u32,
+                       (const float4 *)out_tex, n);
+    RT_AFTER_LAUNCH();
+}
+
+void rt_k_cast_rays(rt_device *dev, const rt_scene_view *sc, rt_mem out_u32, rt_mem ray_o, rt_mem ray_d, uint32_t n)
+{
+    if (!n) return;
+    rt_launch_timer tm(dev, RT_K_CAST_RAYS);
+    hipLaunchKernelGGL(k_cast_rays, dim3(blocks_for(n, 64)), dim3(64), 0, dev->stream, make_scene_dev(sc),
+                       (uint32_t *)out_u32, (const float4 *)ray_o, (const float4 *)ray_d, n);
+    RT_AFTER_LAUNCH();
+}
+
+void rt_k_path_trace(rt_device *dev, const rt_scene_view *sc, rt_mem out_tex, rt_mem ray_d, uint32_t w, uint32_t h,
+                     const float cam_pos[3], uint32_t magic)
+{
+    if (!(w * h)) return;
+    rt_launch_timer tm(dev, RT_K_PATH_TRACE);
+    hipLaunchKernelGGL(k_path_trace, dim3(blocks_for(w, 8), blocks_for(h, 8)), dim3(8, 8), 0, dev->stream,
+                       make_scene_dev(sc), (float4 *)out_tex, (const float4 *)ray_d, w, h, host3(cam_pos), magic);
+    RT_AFTER_LAUNCH();
+}
+
+void rt_k_f_buffer_average(rt_device *dev, rt_mem out_tex, rt_mem fresh, uint32_t n, uint32_t sample)
+{
+    if (!n) return;
+    rt_launch_timer tm(dev, RT_K_F_AVERAGE);
+    hipLaunchKernelGGL(k_f_buffer_average, dim3(blocks_for(n, 256)), dim3(256), 0, dev->stream, (float4 *)out_tex,
+                       (const float4 *)fresh, n, sample);
+    RT_AFTER_LAUNCH();
+}
+
+void rt_k_f_to_byte(rt_device *dev, rt_mem out_u32, rt_mem tex, uint32_t n)
+{
+    if (!n) return;
+    rt_launch_timer tm(dev, RT_K_F_TO_BYTE);
+    hipLaunchKernelGGL(k_f_to_byte, dim3(blocks_for(n, 256)), dim3(256), 0, dev->stream, (uint32_t *)out_u32,
+                       (const float4 *)tex, n);
+    RT_AFTER_LAUNCH();
+}
+
+}  // extern "C"

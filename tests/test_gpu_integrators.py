@@ -1,0 +1,47 @@
+"""GPU parity for the brute-force integrators (SS ray caster, PATH tracer)."""
+import numpy as np
+import pytest
+
+from helpers import assert_bits_equal
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("scene_name", ["sphere_plane", "mixed"])
+def test_ss_cast_rays_bit_exact(rt, orc, scene_name):
+    sc = rt.scenes.sphere_plane_scene() if scene_name == "sphere_plane" else rt.scenes.mixed_scene(2)
+    w, h = (128, 128) if scene_name == "sphere_plane" else (96, 64)
+    r = rt.Renderer(sc, w, h).build()
+    img = r.ss_render()
+    want = orc.cast_ray_test(sc, orc.generate_rays(w, h))
+    assert_bits_equal(img, want, "cast_ray_test image")
+    assert len(np.unique(img)) > 20
+    r.close()
+
+
+def test_path_trace_within_tolerance(rt, orc):
+    """path_trace seeds its RNG through sin() of large arguments, so device and
+    host libm may disagree on a few pixels' seeds; everything else is exact.
+    Tolerance: at most 0.5% of pixels differ, and the image RMSE is below 2e-2."""
+    sc = rt.scenes.mixed_scene(2)
+    w, h = 64, 48
+    r = rt.Renderer(sc, w, h).build()
+    r.init_path(num_samples=3)
+    rays = orc.generate_rays(w, h)
+    out = None
+    for sample in (1, 2, 3):
+        img = r.path_render()
+        fresh = orc.path_trace(sc, rays, w, h, (0, 0, 0), sample)
+        if sample == 1:
+            out = fresh.copy()
+        orc.f_buffer_average(out, fresh, sample)
+        got_fresh = r.download(r.path.contents.cl_path_fresh_frame_buffer, np.float32, 4 * w * h).reshape(-1, 4)
+        differ = (got_fresh.view(np.uint32) != fresh.view(np.uint32)).any(axis=1).mean()
+        assert differ <= 0.005, f"{differ:.4f} of pixels differ in sample {sample}"
+        rmse = float(np.sqrt(np.mean((got_fresh - fresh) ** 2)))
+        assert rmse < 2e-2
+        got_out = r.download(r.path.contents.cl_path_output_buffer, np.float32, 4 * w * h).reshape(-1, 4)
+        if differ == 0:
+            assert_bits_equal(got_out, out, "running mean")
+            assert_bits_equal(img, orc.f_to_byte(out), "packed image")
+    r.close()
