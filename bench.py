@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""Benchmark of the split kd-tree path tracer's render loop on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step is one render iteration (spath_raytracer_render): one bounce of every
+pixel's path = one ray per pixel traced through the kd-tree and shaded.  The
+default workload is the million-triangle configuration the headline metric is
+quoted on: a 1,310,720-triangle displaced icosphere in a room with an emissive
+quad ("c3"), 2048x2048 pixels.  With N > 1 (one process per GPU, launched by
+torch.distributed.run) the frame is split into N row strips, each rank renders
+its strip with the scene replicated, and the resolved strips are gathered to
+rank 0 over RCCL at the end of the timed region; total work is fixed, so the
+scaling is strong.
+
+Rank 0 prints ONE JSON line: Mrays/s of the whole job, the HBM roofline figure
+of the dominant kernel (algorithmic bytes per launch / measured launch time)
+and a CPU baseline (the oracle restatement on a bounded sample, host cores).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak
+B_STREAM = 256.0               # per-ray state streaming, bytes (traversal 48 + shading 180 + RNG 8 + per-sample 20)
+
+WORKLOADS = {
+    # name: (scene factory args, width, height, description)
+    "c3": (("icosphere", 8), 2048, 2048, "1.31M-triangle displaced icosphere + room, 2048x2048, 4 bounces"),
+    "c2": (("icosphere", 6), 1024, 1024, "81,920-triangle displaced icosphere + room, 1024x1024, 4 bounces"),
+    "c5": (("soup", 10_000_000), 3840, 2160, "10M-triangle random soup, 3840x2160"),
+    "tiny": (("icosphere", 4), 256, 256, "5,120-triangle icosphere + room, 256x256 (smoke)"),
+}
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def make_scene(spec):
+    from raytracer_amd import scenes
+    kind, arg = spec
+    if kind == "icosphere":
+        return scenes.icosphere_scene(arg)
+    return scenes.soup_scene(arg)
+
+
+def cpu_baseline(rt, sc, r, width, full_height, threads, target_rays=3_000_000):
+    """Oracle (C restatement, OpenMP) on a bounded sample: a strip of rows
+    around the middle of the same frame, same scene and RNG streams; prepass
+    untimed, then timed iterations.  Uses the serialised tree the library
+    produced (the reference's wire format) so no second tree build is needed."""
+    import oracle
+    from raytracer_amd.scenes import splitmix32
+    kdt = r.kdt
+    blob = np.ctypeslib.as_array(kdt.buffer, shape=(int(kdt.buffer_size),))
+    tree = oracle.KdTree.from_blob(blob, sc.verts4, sc.idx4, kdt.bounds.min[:3], kdt.bounds.max[:3])
+    iters = 6
+    rows = max(1, min(full_height, target_rays // (width * iters)))
+    y0 = (full_height - rows) // 2
+    st = oracle.SpathState(sc, tree, width, rows, y0, full_height)
+    st.nthreads = threads
+    first = y0 * width
+    rb = splitmix32(1, np.arange(first, first + width * rows, dtype=np.uint64))
+    rv = splitmix32(2, np.arange(iters + 1, dtype=np.uint64))
+    st.prepass(rb, int(rv[0]))
+    st.iterate(int(rv[1]))             # the first iteration traces the wiped (null) rays: untimed
+    t0 = time.perf_counter()
+    for k in range(1, iters):
+        st.iterate(int(rv[k + 1]))
+    dt = time.perf_counter() - t0
+    rays = width * rows * (iters - 1)
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"rows {y0}..{y0 + rows - 1} of the {width}x{full_height} frame, {iters - 1} iterations "
+                      f"({rays} rays, {dt:.1f} s), oracle/oracle_rt.c with OpenMP"}
+
+
+def gather_stats(rt, sc, r, threads, sample=262_144):
+    """Average traversal work per ray of the rays now in the GPU's ray buffer
+    (evenly spaced sample), counted by the instrumented oracle."""
+    import oracle
+    n = r.width * r.height
+    b = r.spath_buffers()
+    ro = r.download(b.ray_o, np.float32, 4 * n).reshape(n, 4)
+    rd = r.download(b.ray_d, np.float32, 4 * n).reshape(n, 4)
+    step = max(1, n // sample)
+    rays = np.ascontiguousarray(np.concatenate([ro[::step], rd[::step]], axis=1))
+    kdt = r.kdt
+    blob = np.ctypeslib.as_array(kdt.buffer, shape=(int(kdt.buffer_size),))
+    tree = oracle.KdTree.from_blob(blob, sc.verts4, sc.idx4, kdt.bounds.min[:3], kdt.bounds.max[:3])
+    _, st = tree.intersect(rays, stats=True, nthreads=threads)
+    m = float(st["rays"])
+    per_ray = {k: st[k] / m for k in ("nodes_visited", "leaves_visited", "tri_refs", "tri_tests", "pushes")}
+    per_ray["max_stack"] = st["max_stack"]
+    per_ray["frac_rays_over_16"] = st["rays_over_16"] / m
+    b_gather = per_ray["nodes_visited"] * 8 + per_ray["leaves_visited"] * 8 + per_ray["tri_refs"] * 4 + per_ray["tri_tests"] * 36
+    return per_ray, b_gather
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--workload", default=os.environ.get("RT_BENCH_WORKLOAD", "c3"), choices=sorted(WORKLOADS))
+    ap.add_argument("--separate-kernels", action="store_true", help="three launches per iteration, as the reference")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        log(f"note: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
+    n_gpus = world
+
+    dist = torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import raytracer_amd as rt
+
+    spec, width, height, desc = WORKLOADS[args.workload]
+    if height % world:
+        raise SystemExit(f"height {height} is not divisible by {world} ranks")
+    strip = height // world
+    y0 = rank * strip
+
+    t0 = time.perf_counter()
+    sc = make_scene(spec)
+    t_scene = time.perf_counter() - t0
+    r = rt.Renderer(sc, width, strip, device=local_rank, tile_y0=y0, full_height=height)
+    t0 = time.perf_counter()
+    r.build()
+    t_build = time.perf_counter() - t0
+    r.init_spath(seed=1, separate_kernels=args.separate_kernels, resolve_interval=50, quiet=True)
+    r.spath_prepass(num_iterations=1 << 30)
+    if rank == 0:
+        log(f"[bench] {desc}: {sc.num_tris} triangles, scene {t_scene:.1f}s, build {t_build:.1f}s, "
+            f"{r.kdt.num_nodes_total} nodes, strip {width}x{strip} per rank, device {r.device_props()['name']}")
+
+    def sync_all():
+        r.sync()
+        if torch is not None:
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    r.spath_render(args.warmup)
+    sync_all()
+    r.timing(True)
+    r.timing_reset()
+
+    n_local = width * strip
+    frame = None
+    if torch is not None:
+        frame = torch.empty(n_local, dtype=torch.int32, device=f"cuda:{local_rank}")
+        gathered = [torch.empty_like(frame) for _ in range(world)] if rank == 0 else None
+
+    sync_all()
+    t0 = time.perf_counter()
+    r.spath_render(args.steps)
+    if torch is not None:
+        # resolve this strip, hand it to torch and gather the frame on rank 0 (RCCL)
+        r.L.rt_k_resolve_avg(r.dev, r.rctx.contents.cl_output_buffer, r.spath.contents.cl_path_output_buffer, n_local)
+        r.L.rt_mem_copy(r.dev, frame.data_ptr(), r.rctx.contents.cl_output_buffer, n_local * 4)
+        r.sync()
+        dist.gather(frame, gathered, dst=0)
+    sync_all()
+    dt = time.perf_counter() - t0
+    if torch is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    kname = "spath_iteration" if not args.separate_kernels else "kd_intersect"
+    launches, kms = r.timing_get(kname)
+    r.timing(False)
+
+    if rank == 0:
+        total_rays = width * height * args.steps
+        value = total_rays / dt / 1e6
+        threads = args.cpu_threads or min(16, os.cpu_count() or 1)
+        per_ray, b_gather = gather_stats(rt, sc, r, threads)
+        b_ray = B_STREAM + b_gather
+        avg_ms = kms / max(launches, 1)
+        achieved = (b_ray * n_local) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(f"{args.workload}:{kname}")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mrays/sec (primary+bounce)", "value": round(value, 2), "unit": "Mrays/s",
+            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {desc}", "triangles": int(sc.num_tris), "width": width,
+                       "height": height, "rows_per_gpu": strip, "kernel": kname,
+                       "partition": f"{world} row strips + RCCL gather of the resolved frame" if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel": kname, "avg_launch_ms": round(avg_ms, 4), "launches": launches,
+                         "bytes_per_ray": round(b_ray, 1), "rays_per_launch": n_local,
+                         "per_ray": {k: round(v, 3) for k, v in per_ray.items()}},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(rt, sc, r, width, height, threads)
+            out["cpu_baseline"]["value"] = round(out["cpu_baseline"]["value"], 3)
+        print(json.dumps(out), flush=True)
+
+    if torch is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    r.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -98,9 +98,28 @@ class KdTree:
         self.scene_max = np.zeros(3, np.float32)
         L.orc_scene_bounds_rounded(_p(self.bounds_min), _p(self.bounds_max), _p(self.scene_min), _p(self.scene_max))
 
+    @classmethod
+    def from_blob(cls, blob: np.ndarray, verts4: np.ndarray, idx4: np.ndarray, bounds_min, bounds_max):
+        """Oracle traversal over an already serialised tree (the reference's
+        wire format), e.g. one a caller built elsewhere; no oracle build."""
+        self = cls.__new__(cls)
+        self.verts4 = np.ascontiguousarray(verts4, np.float32)
+        self.idx4 = np.ascontiguousarray(idx4, np.int32)
+        self._h = None
+        self.blob = np.ascontiguousarray(blob, np.uint8)
+        self.blob_size = self.blob_used = int(self.blob.shape[0])
+        self.bounds_min = np.asarray(bounds_min, np.float32).copy()
+        self.bounds_max = np.asarray(bounds_max, np.float32).copy()
+        self.scene_min = np.zeros(3, np.float32)
+        self.scene_max = np.zeros(3, np.float32)
+        lib().orc_scene_bounds_rounded(_p(self.bounds_min), _p(self.bounds_max), _p(self.scene_min), _p(self.scene_max))
+        self.counts = {}
+        return self
+
     def __del__(self):
         try:
-            lib().orc_kd_free(self._h)
+            if self._h is not None:
+                lib().orc_kd_free(self._h)
         except Exception:
             pass
 
