@@ -186,8 +186,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    kname = "spath_iteration" if not args.separate_kernels else "kd_intersect"
+    kname = "kd_intersect"
     launches, kms = r.timing_get(kname)
+    _, shade_ms = r.timing_get("spath_trace")
     r.timing(False)
 
     if rank == 0:
@@ -217,6 +218,7 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": kname, "avg_launch_ms": round(avg_ms, 4), "launches": launches,
                          "bytes_per_ray": round(b_ray, 1), "rays_per_launch": n_local,
+                         "shade_avg_launch_ms": round(shade_ms / max(launches, 1), 4),
                          "per_ray": {k: round(v, 3) for k, v in per_ray.items()}},
         }
         if not args.no_cpu_baseline and world == 1:

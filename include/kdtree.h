@@ -64,11 +64,11 @@ typedef struct kd_tree_node {
 
 /* flattened tree on the host, uploaded by scene_resource_push (layouts: rt_hip.h) */
 typedef struct kd_tree_flat {
-    uint32_t *nodes;        /* 2 words per node */
+    uint32_t *nodes;        /* 4 words per interior node */
     float    *leaf_tris;    /* 12 floats per slot */
-    uint32_t  num_nodes;
+    uint32_t  num_nodes;    /* interior nodes */
     uint32_t  num_leaf_slots;
-    uint32_t  root_is_leaf;
+    uint32_t  root_ref;
 } kd_tree_flat;
 
 /* reference: include/kdtree.h:65-91 */

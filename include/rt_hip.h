@@ -55,8 +55,7 @@ void   rt_mem_copy(rt_device *dev, rt_mem dst, rt_mem src, size_t bytes);       
 /* ---- timing with HIP events on the device's stream ---------------------- */
 enum {
     RT_K_GENERATE_RAYS = 0, RT_K_KD_INTERSECT, RT_K_SPATH_INIT, RT_K_SPATH_TRACE, RT_K_XORSHIFT,
-    RT_K_SPATH_ITERATION, RT_K_RESOLVE_AVG, RT_K_CAST_RAYS, RT_K_PATH_TRACE, RT_K_F_AVERAGE,
-    RT_K_F_TO_BYTE, RT_K_COUNT
+    RT_K_RESOLVE_AVG, RT_K_CAST_RAYS, RT_K_PATH_TRACE, RT_K_F_AVERAGE, RT_K_F_TO_BYTE, RT_K_COUNT
 };
 /* When enabled, every launch below is bracketed by two events; the totals are
    read back (after a sync) with rt_timing_get and cleared with rt_timing_reset. */
@@ -67,14 +66,15 @@ const char *rt_kernel_name(int kernel_id);
 
 /* ---- scene data as the kernels see it ------------------------------------ */
 /* Flattened kd-tree (built by kd_tree_flatten, kdtree.h).
- *   nodes      8 bytes each {u32 w0, u32 w1}.
- *              interior: w0 = float bits of the split position, w1 = right
- *              child index << 2 | axis (0..2); the left child is the next node.
- *              leaf:     w1 & 3 == 3, w1 >> 2 = triangle count, w0 = first slot
- *              in leaf_tris.
+ *   nodes      interior nodes only, 16 bytes each {f32 split, u32 axis, u32 left, u32 right}.
+ *              A child reference is an interior node index (bit 31 clear) or a
+ *              leaf descriptor (bit 31 set): bits 25..0 = first slot in
+ *              leaf_tris, bits 30..26 = triangle count, 31 meaning "31 or more,
+ *              read the count from the leaf's first slot".  Leaves therefore
+ *              cost no node fetch of their own.
  *   leaf_tris  48 bytes per slot, leaf order (a triangle referenced by several
  *              leaves is stored once per leaf): {v0.xyz, index offset as u32 bits},
- *              {v1-v0, 0}, {v2-v0, 0}.
+ *              {v1-v0, triangle count of the leaf as u32 bits}, {v2-v0, 0}.
  *   tri_shade  64 bytes per triangle, indexed by index offset / 3:
  *              {n0.xyz, colour.r}, {n1.xyz, colour.g}, {n2.xyz, colour.b},
  *              {reflectivity, 0, 0, 0}.
@@ -85,10 +85,10 @@ typedef struct rt_kd_view {
     rt_mem nodes;
     rt_mem leaf_tris;
     rt_mem tri_shade;
-    uint32_t num_nodes;
+    uint32_t num_nodes;          /* interior nodes */
     uint32_t num_leaf_slots;
     uint32_t num_tris;
-    uint32_t root_is_leaf;
+    uint32_t root_ref;           /* child reference of the root (a leaf descriptor for a one-leaf tree) */
     float scene_min[3];      /* SCENE_MIN / SCENE_MAX of src/raytracer.c:53-64 */
     float scene_max[3];
 } rt_kd_view;
@@ -126,23 +126,25 @@ typedef struct rt_spath_buffers {
 void rt_k_generate_rays(rt_device *dev, rt_mem ray_o, rt_mem ray_d, uint32_t w, uint32_t h,
                         uint32_t y0, uint32_t full_h, float tan_half_fov);
 
-/* kdtree_intersection (src/kernels/kdtree.cl:90-321; host src/spath_raytracer.c:136-171). */
+/* kdtree_intersection (src/kernels/kdtree.cl:90-321; host src/spath_raytracer.c:136-171).
+   Persistent waves pull rays from a device-side work counter (the reference
+   does the same through dumb_data[16], src/kernels/kdtree.cl:125,160-166); the
+   counter lives in a small buffer owned by the rt_device and is cleared on the
+   stream before every launch. */
 void rt_k_kd_intersect(rt_device *dev, const rt_kd_view *kd, rt_mem ray_o, rt_mem ray_d, rt_mem hits, uint32_t n);
 
 /* segmented_path_trace_init (src/kernels/path.cl:36-113; host src/spath_raytracer.c:280-316). */
 void rt_k_spath_init(rt_device *dev, const rt_kd_view *kd, const rt_spath_buffers *b, uint32_t w, uint32_t h,
                      uint32_t y0, uint32_t random_value);
 
-/* segmented_path_trace (src/kernels/path.cl:115-258; host src/spath_raytracer.c:318-353). */
-void rt_k_spath_trace(rt_device *dev, const rt_kd_view *kd, const rt_spath_buffers *b, uint32_t n, uint32_t random_value);
+/* segmented_path_trace (src/kernels/path.cl:115-258; host src/spath_raytracer.c:318-353).
+   With step_rng != 0 the per-pixel RNG word is advanced first (xorshift_batch
+   folded into this launch) and written back. */
+void rt_k_spath_trace(rt_device *dev, const rt_kd_view *kd, const rt_spath_buffers *b, uint32_t n,
+                      uint32_t random_value, int step_rng);
 
 /* xorshift_batch (src/kernels/path.cl:421-426; host src/spath_raytracer.c:237-250). */
 void rt_k_xorshift(rt_device *dev, rt_mem random, uint32_t n);
-
-/* One whole render iteration -- xorshift_batch, kdtree_intersection and
-   segmented_path_trace for every pixel -- as a single launch
-   (the three launches + clFinish of src/spath_raytracer.c:364-385). */
-void rt_k_spath_iteration(rt_device *dev, const rt_kd_view *kd, const rt_spath_buffers *b, uint32_t n, uint32_t random_value);
 
 /* f_buffer_to_byte_buffer_avg (src/kernels/path.cl:428-444; host src/spath_raytracer.c:252-277). */
 void rt_k_resolve_avg(rt_device *dev, rt_mem out_u32, rt_mem out_tex, uint32_t n);

@@ -45,7 +45,7 @@ typedef struct spath_raytracer_context {
     unsigned int rng_seed;
     unsigned int rng_launch;          /* launches drawn so far */
     unsigned int resolve_interval;    /* resolve + readback every this many iterations (reference: 50) */
-    int          separate_kernels;    /* 1: three launches per iteration as the reference; 0: one fused launch */
+    int          separate_kernels;    /* 1: three launches per iteration as the reference; 0: RNG step folded into shading */
     bool         quiet;
 } spath_raytracer_context;
 

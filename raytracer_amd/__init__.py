@@ -26,8 +26,7 @@ SS_RAYTRACER, PATH_RAYTRACER, SPLIT_PATH_RAYTRACER = 0, 1, 2
 RT_RNG_LIBC, RT_RNG_SPLITMIX = 0, 1
 
 KERNEL_IDS = {"generate_rays": 0, "kd_intersect": 1, "spath_init": 2, "spath_trace": 3, "xorshift": 4,
-              "spath_iteration": 5, "resolve_avg": 6, "cast_rays": 7, "path_trace": 8,
-              "f_buffer_average": 9, "f_to_byte": 10}
+              "resolve_avg": 5, "cast_rays": 6, "path_trace": 7, "f_buffer_average": 8, "f_to_byte": 9}
 
 HIT_DT = np.dtype([("tri", "<u4"), ("t", "<f4"), ("u", "<f4"), ("v", "<f4")])
 
@@ -55,13 +54,13 @@ class AABB(C.Structure):
 
 class kd_tree_flat(C.Structure):
     _fields_ = [("nodes", C.POINTER(C.c_uint32)), ("leaf_tris", C.POINTER(C.c_float)), ("num_nodes", C.c_uint32),
-                ("num_leaf_slots", C.c_uint32), ("root_is_leaf", C.c_uint32)]
+                ("num_leaf_slots", C.c_uint32), ("root_ref", C.c_uint32)]
 
 
 class rt_kd_view(C.Structure):
     _fields_ = [("nodes", C.c_void_p), ("leaf_tris", C.c_void_p), ("tri_shade", C.c_void_p),
                 ("num_nodes", C.c_uint32), ("num_leaf_slots", C.c_uint32), ("num_tris", C.c_uint32),
-                ("root_is_leaf", C.c_uint32), ("scene_min", C.c_float * 3), ("scene_max", C.c_float * 3)]
+                ("root_ref", C.c_uint32), ("scene_min", C.c_float * 3), ("scene_max", C.c_float * 3)]
 
 
 class rt_spath_buffers(C.Structure):
@@ -158,7 +157,7 @@ EXPORTED_SYMBOLS = [
     "rt_device_stream", "rt_device_ordinal", "rt_mem_alloc", "rt_mem_free", "rt_mem_upload", "rt_mem_download",
     "rt_mem_zero", "rt_mem_copy", "rt_timing_enable", "rt_timing_reset", "rt_timing_get", "rt_kernel_name",
     "rt_k_generate_rays", "rt_k_kd_intersect", "rt_k_spath_init", "rt_k_spath_trace", "rt_k_xorshift",
-    "rt_k_spath_iteration", "rt_k_resolve_avg", "rt_k_cast_rays", "rt_k_path_trace", "rt_k_f_buffer_average",
+    "rt_k_resolve_avg", "rt_k_cast_rays", "rt_k_path_trace", "rt_k_f_buffer_average",
     "rt_k_f_to_byte",
     # parallel.h
     "cl_info", "create_context", "load_program_raw", "load_program_url", "gen_rgb_image", "gen_grayscale_buffer",
@@ -238,9 +237,8 @@ def lib():
     L.rt_k_generate_rays.argtypes = [vp, vp, vp, u32, u32, u32, u32, C.c_float]
     L.rt_k_kd_intersect.argtypes = [vp, C.POINTER(rt_kd_view), vp, vp, vp, u32]
     L.rt_k_spath_init.argtypes = [vp, C.POINTER(rt_kd_view), C.POINTER(rt_spath_buffers), u32, u32, u32, u32]
-    L.rt_k_spath_trace.argtypes = [vp, C.POINTER(rt_kd_view), C.POINTER(rt_spath_buffers), u32, u32]
+    L.rt_k_spath_trace.argtypes = [vp, C.POINTER(rt_kd_view), C.POINTER(rt_spath_buffers), u32, u32, C.c_int]
     L.rt_k_xorshift.argtypes = [vp, vp, u32]
-    L.rt_k_spath_iteration.argtypes = [vp, C.POINTER(rt_kd_view), C.POINTER(rt_spath_buffers), u32, u32]
     L.rt_k_resolve_avg.argtypes = [vp, vp, vp, u32]
     L.rt_k_f_buffer_average.argtypes = [vp, vp, vp, u32, u32]
     L.rt_k_f_to_byte.argtypes = [vp, vp, vp, u32]
@@ -315,9 +313,9 @@ class HostKdTree:
         self.bounds_min = np.array(t.bounds.min[:3], np.float32)
         self.bounds_max = np.array(t.bounds.max[:3], np.float32)
         f = t.flat
-        self.nodes = np.ctypeslib.as_array(f.nodes, shape=(f.num_nodes, 2)).copy()
+        self.nodes = np.ctypeslib.as_array(f.nodes, shape=(max(f.num_nodes, 1), 4)).copy()[:f.num_nodes]
         self.leaf_tris = np.ctypeslib.as_array(f.leaf_tris, shape=(max(f.num_leaf_slots, 1), 12)).copy()[:f.num_leaf_slots]
-        self.root_is_leaf = int(f.root_is_leaf)
+        self.root_ref = int(f.root_ref)
 
     def __del__(self):
         try:

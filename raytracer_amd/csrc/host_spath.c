@@ -4,9 +4,9 @@
  *
  * The reference synchronises the host after each of its three launches per
  * iteration and rewrites a small buffer in between; here an iteration is queued
- * without waiting (one fused launch by default) and the host only blocks when
- * the frame is resolved and read back, every resolve_interval iterations and
- * at completion.
+ * without waiting (two launches by default: traversal, then shading with the
+ * RNG step folded in) and the host only blocks when the frame is resolved and
+ * read back, every resolve_interval iterations and at completion.
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -164,9 +164,10 @@ void spath_raytracer_render(spath_raytracer_context *c)
     if (c->separate_kernels) {
         rt_k_xorshift(dev, b.random, n);
         rt_k_kd_intersect(dev, &kdt->view, b.ray_o, b.ray_d, b.hits, n);
-        rt_k_spath_trace(dev, &kdt->view, &b, n, rv);
+        rt_k_spath_trace(dev, &kdt->view, &b, n, rv, 0);
     } else {
-        rt_k_spath_iteration(dev, &kdt->view, &b, n, rv);
+        rt_k_kd_intersect(dev, &kdt->view, b.ray_o, b.ray_d, b.hits, n);
+        rt_k_spath_trace(dev, &kdt->view, &b, n, rv, 1);      /* RNG step folded into the shading launch */
     }
 
     if (c->resolve_interval && c->current_iteration % c->resolve_interval == 0) {

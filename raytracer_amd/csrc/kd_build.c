@@ -438,6 +438,10 @@ void kd_tree_generate_serialized(kd_tree *tree)
 }
 
 /* ---- flattening ---------------------------------------------------------- */
+#define REF_LEAF        0x80000000u
+#define REF_SLOT_BITS   26
+#define REF_COUNT_MAX   31u
+
 typedef struct flat_ctx {
     kd_tree_flat *f;
     const float (*verts)[4];
@@ -445,15 +449,13 @@ typedef struct flat_ctx {
     uint32_t next_node, next_slot, depth_max;
 } flat_ctx;
 
-static void flatten_rec(flat_ctx *fc, const kd_tree_node *n, uint32_t depth)
+/* returns the child reference of n (layout: rt_hip.h) */
+static uint32_t flatten_rec(flat_ctx *fc, const kd_tree_node *n, uint32_t depth)
 {
-    const uint32_t self = fc->next_node++;
-    uint32_t *w = fc->f->nodes + 2 * (size_t)self;
     if (depth > fc->depth_max) fc->depth_max = depth;
     if (!n->left) {
         const uint32_t cnt = n->triangles.num_triangles;
-        w[0] = fc->next_slot;
-        w[1] = (cnt << 2) | 3u;
+        const uint32_t start = fc->next_slot;
         for (uint32_t i = 0; i < cnt; i++) {
             const unsigned int off = n->triangles.triangle_buffer[i];
             const float *a = fc->verts[fc->idx[off][0]];
@@ -461,16 +463,20 @@ static void flatten_rec(flat_ctx *fc, const kd_tree_node *n, uint32_t depth)
             const float *c = fc->verts[fc->idx[off + 2][0]];
             float *o = fc->f->leaf_tris + 12 * (size_t)fc->next_slot++;
             o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; memcpy(&o[3], &off, 4);
-            o[4] = b[0] - a[0]; o[5] = b[1] - a[1]; o[6] = b[2] - a[2]; o[7] = 0.f;
+            o[4] = b[0] - a[0]; o[5] = b[1] - a[1]; o[6] = b[2] - a[2]; memcpy(&o[7], &cnt, 4);
             o[8] = c[0] - a[0]; o[9] = c[1] - a[1]; o[10] = c[2] - a[2]; o[11] = 0.f;
         }
-        return;
+        return REF_LEAF | ((cnt < REF_COUNT_MAX ? cnt : REF_COUNT_MAX) << REF_SLOT_BITS) | (cnt ? start : 0u);
     }
+    const uint32_t self = fc->next_node++;
+    const uint32_t l = flatten_rec(fc, n->left, depth + 1);
+    const uint32_t r = flatten_rec(fc, n->right, depth + 1);
+    uint32_t *w = fc->f->nodes + 4 * (size_t)self;
     memcpy(&w[0], &n->b, 4);
-    flatten_rec(fc, n->left, depth + 1);          /* the left child is always self + 1 */
-    const uint32_t right = fc->next_node;
-    w[1] = (right << 2) | (uint32_t)(n->k > 2 ? 2 : n->k);
-    flatten_rec(fc, n->right, depth + 1);
+    w[1] = (uint32_t)(n->k > 2 ? 2 : n->k);
+    w[2] = l;
+    w[3] = r;
+    return self;
 }
 
 void kd_tree_flatten(kd_tree *tree)
@@ -479,21 +485,21 @@ void kd_tree_flatten(kd_tree *tree)
     free(f->nodes); free(f->leaf_tris);
     memset(f, 0, sizeof *f);
     if (!tree->root) return;
-    if (tree->num_nodes_total >= (1u << 30) || tree->num_indices_total >= (1u << 30)) {
-        fprintf(stderr, "ERROR: kd-tree too large for the 30-bit node/count fields\n");
+    if (tree->num_traversal_nodes >= REF_LEAF || tree->num_indices_total >= (1u << REF_SLOT_BITS)) {
+        fprintf(stderr, "ERROR: kd-tree too large for the flattened layout (%u interior nodes, %u leaf slots)\n",
+                tree->num_traversal_nodes, tree->num_indices_total);
         exit(1);
     }
-    f->num_nodes = tree->num_nodes_total;
+    f->num_nodes = tree->num_traversal_nodes;
     f->num_leaf_slots = tree->num_indices_total;
-    f->nodes = (uint32_t *)malloc(sizeof(uint32_t) * 2 * (size_t)f->num_nodes);
+    f->nodes = (uint32_t *)malloc(sizeof(uint32_t) * 4 * (size_t)(f->num_nodes ? f->num_nodes : 1));
     f->leaf_tris = (float *)malloc(sizeof(float) * 12 * (size_t)(f->num_leaf_slots ? f->num_leaf_slots : 1));
-    f->root_is_leaf = tree->root->left == NULL;
     flat_ctx fc;
     fc.f = f;
     fc.verts = (const float (*)[4])tree->s->mesh_verts;
     fc.idx = (const int (*)[4])tree->s->mesh_indices;
     fc.next_node = fc.next_slot = fc.depth_max = 0;
-    flatten_rec(&fc, tree->root, 0);
+    f->root_ref = flatten_rec(&fc, tree->root, 0);
     if (fc.depth_max >= 64) {        /* the traversal stack holds 64 entries */
         fprintf(stderr, "ERROR: kd-tree depth %u exceeds the traversal stack\n", fc.depth_max);
         exit(1);

@@ -4,7 +4,7 @@
 #include <cstring>
 
 static const char *k_kernel_names[RT_K_COUNT] = {
-    "generate_rays", "kd_intersect", "spath_init", "spath_trace", "xorshift", "spath_iteration",
+    "generate_rays", "kd_intersect", "spath_init", "spath_trace", "xorshift",
     "resolve_avg", "cast_rays", "path_trace", "f_buffer_average", "f_to_byte"};
 
 extern "C" {
@@ -32,6 +32,8 @@ rt_device *rt_device_open(int ordinal)
     RT_HIP_CHECK(hipSetDevice(ordinal));
     RT_HIP_CHECK(hipGetDeviceProperties(&dev->props, ordinal));
     RT_HIP_CHECK(hipStreamCreateWithFlags(&dev->stream, hipStreamNonBlocking));
+    RT_HIP_CHECK(hipMalloc((void **)&dev->counters, 256));
+    RT_HIP_CHECK(hipMemset(dev->counters, 0, 256));
     return dev;
 }
 
@@ -46,6 +48,7 @@ void rt_device_close(rt_device *dev)
     }
     for (hipEvent_t e : dev->free_events) (void)hipEventDestroy(e);
     RT_HIP_CHECK(hipStreamDestroy(dev->stream));
+    RT_HIP_CHECK(hipFree(dev->counters));
     delete dev;
 }
 

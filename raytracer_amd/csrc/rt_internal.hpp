@@ -35,6 +35,7 @@ struct rt_device {
     int timing = 0;
     rt_timing_slot slots[RT_K_COUNT];
     std::vector<hipEvent_t> free_events;
+    uint32_t *counters = nullptr;   // device words the kernels use as work counters (256 bytes)
 };
 
 // Brackets one launch with events when timing is on.

@@ -122,113 +122,208 @@ __device__ __forceinline__ bool tri_hit_edges(f3 v0, f3 ab, f3 ac, f3 o, f3 d, f
 struct Hit { uint32_t tri; float t, u, v; };
 
 // ---------------------------------------------------------------------------
-// kd-tree traversal of one ray per lane.
+// kd-tree traversal, one ray per lane, persistent waves.
 //
-// Follows the reference walk (src/kernels/kdtree.cl:188-318) decision for
-// decision: slab clip against the scene box, near/far choice by
-// "o<b || (o==b && d<=0)", near only when t_split > t_max or <= 0, far only
+// Decisions follow the reference walk (src/kernels/kdtree.cl:188-318) one for
+// one: slab clip against the scene box; near/far choice by
+// "o<b || (o==b && d<=0)"; near only when t_split > t_max or <= 0, far only
 // when t_split < t_min, otherwise push the far child; in a leaf the triangles
 // are tested in stored order and the walk stops at the first accepted hit that
 // lies before the leaf's exit distance.  The reference's restart-from-root
-// only ever fires on entry, so it is the loop's first iteration here.
+// only ever fires on entry.
 //
-// Stack entries are {far node, t_split}: an entry's t_max always equals the
+// What is different is the control structure.  The reference nests three
+// data-dependent loops (pop / descend / leaf), which on a 64-wide wave leaves
+// most lanes waiting for the longest one at every level.  Here every lane is a
+// small state machine and the wave runs ONE flat loop: per trip, lanes that sit
+// on an interior node take one descend step, lanes that sit in a leaf test one
+// triangle (and pop when the leaf is used up), and lanes whose ray has finished
+// are handed new rays from a global work counter once enough of them are idle
+// (ballot + prefix rank).  All memory a lane needs for its next step -- the
+// next node, or the next triangle of its leaf -- is requested at the end of the
+// current trip, so a trip costs one memory round trip shared by all 64 lanes.
+//
+// Stack entries are {far child, t_split}: an entry's t_max always equals the
 // t_split of the entry below it (scene_t_max for the bottom one), so it is not
 // stored.  The first LDS_DEPTH entries of each lane live in LDS, laid out
 // [level][lane] so that a wave's accesses never collide on a bank whatever the
 // lanes' depths are; deeper entries (rare) spill to a per-lane private array.
 // ---------------------------------------------------------------------------
 #define RT_MAX_STACK 64
+#define RT_REF_LEAF 0x80000000u
+#define RT_REF_SLOT_MASK 0x03ffffffu
+#define RT_REF_COUNT(ref) (((ref) >> 26) & 31u)
 
-template <int LDS_DEPTH>
-__device__ __forceinline__ Hit kd_trace(const uint2 *__restrict__ nodes, const float4 *__restrict__ leaf_tris,
-                                        f3 o, f3 d, f3 smin, f3 smax, uint32_t root_is_leaf,
-                                        uint2 *__restrict__ lds_col)
+struct TravScene {
+    const uint4 *nodes;
+    const float4 *leaf_tris;
+    f3 smin, smax;
+    uint32_t root_ref;
+};
+
+template <int LDS_DEPTH, int REFILL_MIN, int CHUNK>
+__global__ __launch_bounds__(64) void k_kd_intersect(TravScene P, const float4 *__restrict__ ray_o,
+                                                     const float4 *__restrict__ ray_d, Hit *__restrict__ hits,
+                                                     uint32_t n, uint32_t *__restrict__ counter)
 {
+    __shared__ uint2 stack[LDS_DEPTH * 64];
     uint2 spill[RT_MAX_STACK - LDS_DEPTH];
+    const uint32_t lane = threadIdx.x;
+    uint2 *const col = stack + lane;
 
-    // get_elem (kdtree.cl:67-75) adds the masked-out zeros, which turns -0 into +0
-    const float ocx = o.x + 0.0f, ocy = o.y + 0.0f, ocz = o.z + 0.0f;
-    const float dcx = d.x + 0.0f, dcy = d.y + 0.0f, dcz = d.z + 0.0f;
+    // wave-uniform: the chunk of ray indices this wave is handing out
+    uint32_t chunk_next = 0, chunk_end = 0;
+    bool exhausted = false;
 
-    float t_hit = RT_INF, hu = 0.f, hv = 0.f;
-    uint32_t tri_indx = 0;
+    // per-lane ray state
+    bool active = false;
+    uint32_t ridx = 0, sp = 0, tri_indx = 0;
+    f3 o = mk3(0.f, 0.f, 0.f), d = mk3(0.f, 0.f, 0.f);
+    float t_min = 0.f, t_max = 0.f, scene_t_max = 0.f, t_hit = RT_INF, hu = 0.f, hv = 0.f;
+    uint32_t ref = 0;                       // where the lane stands: interior index or leaf descriptor
+    uint4 node = make_uint4(0, 0, 0, 0);    // the interior node at ref
+    uint32_t li = 0, lc = 0, slot = 0;      // leaf progress: triangle li of lc, first slot
+    float4 T0 = make_float4(0, 0, 0, 0), T1 = T0, T2 = T0;   // triangle li of the leaf
 
-    // getTBoundingBox, reference: src/kernels/collision.cl:71-86
-    float scene_t_min = 0.f, scene_t_max = RT_INF;
-    {
-        f3 inv = mk3(1 / d.x, 1 / d.y, 1 / d.z);
-        f3 t0 = (smin - o) * inv, t1 = (smax - o) * inv;
-        f3 sm = mk3(cl_min(t0.x, t1.x), cl_min(t0.y, t1.y), cl_min(t0.z, t1.z));
-        f3 bg = mk3(cl_max(t0.x, t1.x), cl_max(t0.y, t1.y), cl_max(t0.z, t1.z));
-        scene_t_min = cl_max(scene_t_min, cl_max(sm.x, cl_max(sm.y, sm.z)));
-        scene_t_max = cl_min(scene_t_max, cl_min(bg.x, cl_min(bg.y, bg.z)));
-        if (!(scene_t_min < scene_t_max)) scene_t_max = -RT_INF;
-    }
-    float t_min = scene_t_min, t_max = scene_t_min;
-    uint32_t sp = 0;
-    bool early = false;
+    for (;;) {
+        bool entered = false;               // lane moved to a new ref this trip: fetch what stands there
 
-    while (t_max < scene_t_max && !early) {
-        uint32_t cur;
-        if (sp == 0) {
-            cur = 0; t_min = t_max; t_max = scene_t_max;
-        } else {
-            sp--;
-            uint2 e = (sp < LDS_DEPTH) ? lds_col[sp * 64] : spill[sp - LDS_DEPTH];
-            cur = e.x;
-            t_min = __uint_as_float(e.y);
-            if (sp == 0) t_max = scene_t_max;
-            else {
-                uint2 below = (sp - 1 < LDS_DEPTH) ? lds_col[(sp - 1) * 64] : spill[sp - 1 - LDS_DEPTH];
-                t_max = __uint_as_float(below.y);
+        // ---- hand new rays to idle lanes -----------------------------------
+        const unsigned long long idle = __ballot(!active);
+        const uint32_t nidle = (uint32_t)__popcll(idle);
+        if (!exhausted && nidle >= (uint32_t)REFILL_MIN) {
+            if (chunk_next >= chunk_end) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(counter, (uint32_t)CHUNK);
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                if (base >= n) exhausted = true;
+                else { chunk_next = base; chunk_end = (n - base < (uint32_t)CHUNK) ? n : base + (uint32_t)CHUNK; }
+            }
+            if (!exhausted) {
+                const uint32_t avail = chunk_end - chunk_next;
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32),
+                                                                __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                if (!active && rank < avail) {
+                    ridx = chunk_next + rank;
+                    o = xyz(ray_o[ridx]);
+                    d = xyz(ray_d[ridx]);
+                    // getTBoundingBox, reference: src/kernels/collision.cl:71-86
+                    float scene_t_min = 0.f;
+                    scene_t_max = RT_INF;
+                    f3 inv = mk3(1 / d.x, 1 / d.y, 1 / d.z);
+                    f3 t0 = (P.smin - o) * inv, t1 = (P.smax - o) * inv;
+                    f3 sm = mk3(cl_min(t0.x, t1.x), cl_min(t0.y, t1.y), cl_min(t0.z, t1.z));
+                    f3 bg = mk3(cl_max(t0.x, t1.x), cl_max(t0.y, t1.y), cl_max(t0.z, t1.z));
+                    scene_t_min = cl_max(scene_t_min, cl_max(sm.x, cl_max(sm.y, sm.z)));
+                    scene_t_max = cl_min(scene_t_max, cl_min(bg.x, cl_min(bg.y, bg.z)));
+                    if (!(scene_t_min < scene_t_max)) scene_t_max = -RT_INF;
+                    t_hit = RT_INF; hu = 0.f; hv = 0.f; tri_indx = 0; sp = 0;
+                    t_min = t_max = scene_t_min;
+                    if (t_max < scene_t_max) {          // first pass of the reference's outer loop: start at the root
+                        t_min = t_max; t_max = scene_t_max;
+                        ref = P.root_ref;
+                        entered = true;
+                        active = true;
+                    } else {
+                        Hit miss; miss.tri = 0; miss.t = 0.f; miss.u = 0.f; miss.v = 0.f;
+                        hits[ridx] = miss;
+                    }
+                }
+                chunk_next += (nidle < avail) ? nidle : avail;
+            }
+        }
+        if (!__any(active)) {
+            if (exhausted) break;
+            continue;
+        }
+
+        // ---- one step per lane ----------------------------------------------
+        if (active && !entered) {
+            bool finished = false;
+            if (!(ref & RT_REF_LEAF)) {
+                // descend, reference: src/kernels/kdtree.cl:229-260.  get_elem (:67-75)
+                // adds the masked-out zeros, which turns -0 into +0.
+                const uint32_t k = node.y;
+                const float b = __uint_as_float(node.x);
+                const float ok = ((k == 0) ? o.x : ((k == 1) ? o.y : o.z)) + 0.0f;
+                const float dk = ((k == 0) ? d.x : ((k == 1) ? d.y : d.z)) + 0.0f;
+                const float t_split = (b - ok) / dk;
+                const bool left_close = (ok < b) || (ok == b && dk <= 0);
+                const uint32_t first = left_close ? node.z : node.w;
+                const uint32_t second = left_close ? node.w : node.z;
+                const bool c1 = (t_split > t_max || t_split <= 0);
+                const bool c2 = (t_split < t_min);
+                ref = (c1 || !c2) ? first : second;
+                if (!c1 && !c2) {
+                    const uint2 e = make_uint2(second, __float_as_uint(t_split));
+                    if (sp < (uint32_t)LDS_DEPTH) col[sp * 64] = e;
+                    else if (sp < RT_MAX_STACK) spill[sp - LDS_DEPTH] = e;
+                    sp++;
+                    t_max = t_split;
+                }
+                entered = true;
+            } else {
+                // leaf, reference: src/kernels/kdtree.cl:263-302
+                if (li < lc) {
+                    if (li == 0 && lc == 31u) lc = __float_as_uint(T1.w);
+                    float t, u, v;
+                    if (tri_hit_edges(xyz(T0), xyz(T1), xyz(T2), o, d, t, u, v)) {
+                        if (!(t <= 0) && t < t_hit) {
+                            t_hit = t; hu = u; hv = v; tri_indx = __float_as_uint(T0.w);
+                            if (t_hit < t_max) finished = true;
+                        }
+                    }
+                    li++;
+                    if (!finished && li < lc) {
+                        const float4 *tp = P.leaf_tris + 3 * (size_t)(slot + li);
+                        T0 = tp[0]; T1 = tp[1]; T2 = tp[2];
+                    }
+                }
+                if (!finished && li >= lc) {
+                    // leaf used up: the reference's outer loop test, then restart or pop
+                    if ((P.root_ref & RT_REF_LEAF) || !(t_max < scene_t_max)) finished = true;
+                    else if (sp == 0) {
+                        ref = P.root_ref; t_min = t_max; t_max = scene_t_max;
+                        entered = true;
+                    } else {
+                        sp--;
+                        const uint2 e = (sp < (uint32_t)LDS_DEPTH) ? col[sp * 64] : spill[sp - LDS_DEPTH];
+                        ref = e.x;
+                        t_min = __uint_as_float(e.y);
+                        if (sp == 0) t_max = scene_t_max;
+                        else {
+                            const uint2 below = (sp - 1 < (uint32_t)LDS_DEPTH) ? col[(sp - 1) * 64] : spill[sp - 1 - LDS_DEPTH];
+                            t_max = __uint_as_float(below.y);
+                        }
+                        entered = true;
+                    }
+                }
+            }
+            if (finished) {
+                Hit h;
+                if (!isinf(t_hit)) { h.tri = tri_indx; h.t = t_hit; h.u = hu; h.v = hv; }
+                else { h.tri = 0; h.t = 0.f; h.u = 0.f; h.v = 0.f; }
+                hits[ridx] = h;
+                active = false;
+                entered = false;
             }
         }
 
-        uint2 node = nodes[cur];
-        while ((node.y & 3u) != 3u) {
-            const uint32_t k = node.y & 3u;
-            const float b = __uint_as_float(node.x);
-            const float ok = (k == 0) ? ocx : ((k == 1) ? ocy : ocz);
-            const float dk = (k == 0) ? dcx : ((k == 1) ? dcy : dcz);
-            const float t_split = (b - ok) / dk;
-            const bool left_close = (ok < b) || (ok == b && dk <= 0);
-            const uint32_t left = cur + 1, right = node.y >> 2;
-            const uint32_t first = left_close ? left : right;
-            const uint32_t second = left_close ? right : left;
-            const bool c1 = (t_split > t_max || t_split <= 0);
-            const bool c2 = (t_split < t_min);
-            cur = (c1 || !c2) ? first : second;
-            if (!c1 && !c2) {
-                uint2 e = make_uint2(second, __float_as_uint(t_split));
-                if (sp < LDS_DEPTH) lds_col[sp * 64] = e;
-                else if (sp < RT_MAX_STACK) spill[sp - LDS_DEPTH] = e;
-                sp++;
-                t_max = t_split;
-            }
-            node = nodes[cur];
-        }
-
-        const uint32_t count = node.y >> 2;
-        const float4 *tp = leaf_tris + 3 * (size_t)node.x;
-        for (uint32_t i = 0; i < count; i++, tp += 3) {
-            const float4 a = tp[0], e1 = tp[1], e2 = tp[2];
-            float t, u, v;
-            if (tri_hit_edges(xyz(a), xyz(e1), xyz(e2), o, d, t, u, v)) {
-                if (t <= 0) continue;
-                if (t < t_hit) {
-                    t_hit = t; hu = u; hv = v; tri_indx = __float_as_uint(a.w);
-                    if (t_hit < t_max) { early = true; break; }
+        // ---- request what stands at the lane's new position -------------------
+        if (active && entered) {
+            if (!(ref & RT_REF_LEAF)) {
+                node = P.nodes[ref];
+            } else {
+                lc = RT_REF_COUNT(ref);
+                slot = ref & RT_REF_SLOT_MASK;
+                li = 0;
+                if (lc) {
+                    const float4 *tp = P.leaf_tris + 3 * (size_t)slot;
+                    T0 = tp[0]; T1 = tp[1]; T2 = tp[2];
                 }
             }
         }
-        if (root_is_leaf) break;
     }
-
-    Hit h;
-    if (!isinf(t_hit)) { h.tri = tri_indx; h.t = t_hit; h.u = hu; h.v = hv; }
-    else { h.tri = 0; h.t = 0.f; h.u = 0.f; h.v = 0.f; }
-    return h;
 }
 
 // Surface data of a hit: interpolated (unnormalised) normal, material colour
@@ -307,8 +402,6 @@ __device__ __forceinline__ void spath_step(const float4 *__restrict__ tri_shade,
 // ---------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------
-constexpr int kTraverseLdsDepth = 16;
-
 // generate_rays, reference: src/kernels/ray.cl:109-133.  The reference's 0.5
 // literals are doubles, so the camera-plane coordinates go through double.
 __global__ void k_generate_rays(float4 *__restrict__ ray_o, float4 *__restrict__ ray_d, uint32_t w, uint32_t h,
@@ -323,20 +416,6 @@ __global__ void k_generate_rays(float4 *__restrict__ ray_o, float4 *__restrict__
     f3 dir = normalize3(mk3(cam_x, cam_y, -1.0f));
     ray_o[id] = make_float4(0.f, 0.f, 0.f, 0.f);
     ray_d[id] = mk4(dir, 0.f);
-}
-
-__global__ __launch_bounds__(64) void k_kd_intersect(const uint2 *__restrict__ nodes,
-                                                     const float4 *__restrict__ leaf_tris,
-                                                     const float4 *__restrict__ ray_o,
-                                                     const float4 *__restrict__ ray_d, Hit *__restrict__ hits,
-                                                     uint32_t n, f3 smin, f3 smax, uint32_t root_is_leaf)
-{
-    __shared__ uint2 stack[kTraverseLdsDepth * 64];
-    uint32_t i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= n) return;
-    Hit h = kd_trace<kTraverseLdsDepth>(nodes, leaf_tris, xyz(ray_o[i]), xyz(ray_d[i]), smin, smax, root_is_leaf,
-                                        stack + threadIdx.x);
-    hits[i] = h;
 }
 
 // segmented_path_trace_init, reference: src/kernels/path.cl:36-113.  The
@@ -380,15 +459,24 @@ __global__ void k_spath_init(const float4 *__restrict__ tri_shade, float4 *__res
 }
 
 // segmented_path_trace, reference: src/kernels/path.cl:115-258
+// STEP_RNG folds xorshift_batch (src/kernels/path.cl:421-426) into this launch:
+// the pixel's RNG word is advanced and stored before it is used, exactly as if
+// that kernel had run just before.
+template <bool STEP_RNG>
 __global__ void k_spath_trace(const float4 *__restrict__ tri_shade, float4 *__restrict__ out_tex,
                               float4 *__restrict__ ray_o, float4 *__restrict__ ray_d,
                               const float4 *__restrict__ origin_o, const float4 *__restrict__ origin_d,
                               const Hit *__restrict__ hits, const Hit *__restrict__ source_hits,
                               float4 *__restrict__ prog_a, float4 *__restrict__ prog_b,
-                              const uint32_t *__restrict__ random, uint32_t n, uint32_t random_value)
+                              uint32_t *__restrict__ random, uint32_t n, uint32_t random_value)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    uint32_t rnd = random[i];
+    if (STEP_RNG) {
+        rnd = ((rnd << 1) | (rnd >> 31)) + 1;
+        random[i] = rnd;
+    }
     float4 pa = prog_a[i], pb = prog_b[i];
     if (__float_as_uint(pa.w) == 2048u) {       // reference: path.cl:145-152
         ray_o[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -396,7 +484,7 @@ __global__ void k_spath_trace(const float4 *__restrict__ tri_shade, float4 *__re
         return;
     }
     f3 no, nd;
-    spath_step(tri_shade, hits[i], xyz(ray_o[i]), xyz(ray_d[i]), random[i], random_value, i, out_tex, origin_o,
+    spath_step(tri_shade, hits[i], xyz(ray_o[i]), xyz(ray_d[i]), rnd, random_value, i, out_tex, origin_o,
                origin_d, source_hits, pa, pb, no, nd);
     ray_o[i] = mk4(no, 0.f);
     ray_d[i] = mk4(nd, 0.f);
@@ -411,44 +499,6 @@ __global__ void k_xorshift(uint32_t *__restrict__ data, uint32_t n)
     if (i >= n) return;
     uint32_t d = data[i];
     data[i] = ((d << 1) | (d >> 31)) + 1;
-}
-
-// One render iteration per pixel in a single launch: RNG step, traversal of
-// the pixel's current ray, shading / path regeneration.  Same per-pixel
-// sequence as the three reference launches (src/spath_raytracer.c:364-385);
-// the hit record is also stored so the buffers end up as those launches
-// leave them.
-__global__ __launch_bounds__(64) void k_spath_iteration(
-    const uint2 *__restrict__ nodes, const float4 *__restrict__ leaf_tris, const float4 *__restrict__ tri_shade,
-    float4 *__restrict__ out_tex, float4 *__restrict__ ray_o, float4 *__restrict__ ray_d,
-    const float4 *__restrict__ origin_o, const float4 *__restrict__ origin_d, Hit *__restrict__ hits,
-    const Hit *__restrict__ source_hits, float4 *__restrict__ prog_a, float4 *__restrict__ prog_b,
-    uint32_t *__restrict__ random, uint32_t n, uint32_t random_value, f3 smin, f3 smax, uint32_t root_is_leaf)
-{
-    __shared__ uint2 stack[kTraverseLdsDepth * 64];
-    uint32_t i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= n) return;
-
-    uint32_t rnd = random[i];
-    rnd = ((rnd << 1) | (rnd >> 31)) + 1;
-    random[i] = rnd;
-
-    f3 o = xyz(ray_o[i]), d = xyz(ray_d[i]);
-    Hit h = kd_trace<kTraverseLdsDepth>(nodes, leaf_tris, o, d, smin, smax, root_is_leaf, stack + threadIdx.x);
-    hits[i] = h;
-
-    float4 pa = prog_a[i], pb = prog_b[i];
-    if (__float_as_uint(pa.w) == 2048u) {
-        ray_o[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        ray_d[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        return;
-    }
-    f3 no, nd;
-    spath_step(tri_shade, h, o, d, rnd, random_value, i, out_tex, origin_o, origin_d, source_hits, pa, pb, no, nd);
-    ray_o[i] = mk4(no, 0.f);
-    ray_d[i] = mk4(nd, 0.f);
-    prog_a[i] = pa;
-    prog_b[i] = pb;
 }
 
 // f_buffer_to_byte_buffer_avg, reference: src/kernels/path.cl:428-444
@@ -717,9 +767,48 @@ SceneDev make_scene_dev(const rt_scene_view *sc)
 
 void check_kd(const rt_kd_view *kd, const char *who)
 {
-    if (!kd || !kd->nodes || !kd->leaf_tris || !kd->tri_shade || kd->num_nodes == 0) {
+    if (!kd || !kd->nodes || !kd->leaf_tris || !kd->tri_shade || kd->num_tris == 0) {
         fprintf(stderr, "ERROR: %s: the flattened kd-tree has not been uploaded (no mesh triangles in the scene?)\n", who);
         exit(1);
+    }
+}
+
+// Launch geometry of the persistent traversal kernel: as many one-wave blocks
+// as the chip keeps resident for this kernel (LDS-limited), never more than
+// there are 64-ray groups.  RT_TRAVERSE_VARIANT (environment, read once)
+// selects one of a few compiled parameter sets for tuning runs.
+template <int LDS_DEPTH, int REFILL_MIN, int CHUNK>
+void launch_kd_variant(rt_device *dev, const TravScene &P, const float4 *ro, const float4 *rd, Hit *hits, uint32_t n)
+{
+    auto kern = k_kd_intersect<LDS_DEPTH, REFILL_MIN, CHUNK>;
+    static int blocks_per_cu = 0;
+    if (!blocks_per_cu) {
+        RT_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kern, 64, 0));
+        if (blocks_per_cu < 1) blocks_per_cu = 1;
+    }
+    unsigned grid = (unsigned)blocks_per_cu * (unsigned)dev->props.multiProcessorCount;
+    const unsigned need = blocks_for(n, 64);
+    if (grid > need) grid = need;
+    RT_HIP_CHECK(hipMemsetAsync(dev->counters, 0, sizeof(uint32_t), dev->stream));
+    rt_launch_timer tm(dev, RT_K_KD_INTERSECT);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, dev->stream, P, ro, rd, hits, n, dev->counters);
+    RT_HIP_CHECK(hipGetLastError());
+}
+
+void launch_kd_intersect(rt_device *dev, const TravScene &P, const float4 *ro, const float4 *rd, Hit *hits, uint32_t n)
+{
+    static int variant = -1;
+    if (variant < 0) {
+        const char *e = getenv("RT_TRAVERSE_VARIANT");
+        variant = e ? atoi(e) : 0;
+    }
+    switch (variant) {
+    case 1: launch_kd_variant<12, 16, 256>(dev, P, ro, rd, hits, n); break;
+    case 2: launch_kd_variant<16, 32, 256>(dev, P, ro, rd, hits, n); break;
+    case 3: launch_kd_variant<8, 16, 256>(dev, P, ro, rd, hits, n); break;
+    case 4: launch_kd_variant<16, 8, 256>(dev, P, ro, rd, hits, n); break;
+    case 5: launch_kd_variant<10, 24, 512>(dev, P, ro, rd, hits, n); break;
+    default: launch_kd_variant<16, 16, 256>(dev, P, ro, rd, hits, n); break;
     }
 }
 
@@ -744,11 +833,13 @@ void rt_k_kd_intersect(rt_device *dev, const rt_kd_view *kd, rt_mem ray_o, rt_me
 {
     if (!n) return;
     check_kd(kd, "rt_k_kd_intersect");
-    rt_launch_timer tm(dev, RT_K_KD_INTERSECT);
-    hipLaunchKernelGGL(k_kd_intersect, dim3(blocks_for(n, 64)), dim3(64), 0, dev->stream, (const uint2 *)kd->nodes,
-                       (const float4 *)kd->leaf_tris, (const float4 *)ray_o, (const float4 *)ray_d, (Hit *)hits, n,
-                       host3(kd->scene_min), host3(kd->scene_max), kd->root_is_leaf);
-    RT_AFTER_LAUNCH();
+    TravScene P;
+    P.nodes = (const uint4 *)kd->nodes;
+    P.leaf_tris = (const float4 *)kd->leaf_tris;
+    P.smin = host3(kd->scene_min);
+    P.smax = host3(kd->scene_max);
+    P.root_ref = kd->root_ref;
+    launch_kd_intersect(dev, P, (const float4 *)ray_o, (const float4 *)ray_d, (Hit *)hits, n);
 }
 
 void rt_k_spath_init(rt_device *dev, const rt_kd_view *kd, const rt_spath_buffers *b, uint32_t w, uint32_t h,
@@ -764,16 +855,18 @@ void rt_k_spath_init(rt_device *dev, const rt_kd_view *kd, const rt_spath_buffer
     RT_AFTER_LAUNCH();
 }
 
-void rt_k_spath_trace(rt_device *dev, const rt_kd_view *kd, const rt_spath_buffers *b, uint32_t n, uint32_t random_value)
+void rt_k_spath_trace(rt_device *dev, const rt_kd_view *kd, const rt_spath_buffers *b, uint32_t n,
+                      uint32_t random_value, int step_rng)
 {
     if (!n) return;
     check_kd(kd, "rt_k_spath_trace");
     rt_launch_timer tm(dev, RT_K_SPATH_TRACE);
-    hipLaunchKernelGGL(k_spath_trace, dim3(blocks_for(n, 256)), dim3(256), 0, dev->stream,
+    auto kern = step_rng ? k_spath_trace<true> : k_spath_trace<false>;
+    hipLaunchKernelGGL(kern, dim3(blocks_for(n, 256)), dim3(256), 0, dev->stream,
                        (const float4 *)kd->tri_shade, (float4 *)b->out_tex, (float4 *)b->ray_o, (float4 *)b->ray_d,
                        (const float4 *)b->origin_o, (const float4 *)b->origin_d, (const Hit *)b->hits,
                        (const Hit *)b->source_hits, (float4 *)b->prog_a, (float4 *)b->prog_b,
-                       (const uint32_t *)b->random, n, random_value);
+                       (uint32_t *)b->random, n, random_value);
     RT_AFTER_LAUNCH();
 }
 
@@ -782,21 +875,6 @@ void rt_k_xorshift(rt_device *dev, rt_mem random, uint32_t n)
     if (!n) return;
     rt_launch_timer tm(dev, RT_K_XORSHIFT);
     hipLaunchKernelGGL(k_xorshift, dim3(blocks_for(n, 256)), dim3(256), 0, dev->stream, (uint32_t *)random, n);
-    RT_AFTER_LAUNCH();
-}
-
-void rt_k_spath_iteration(rt_device *dev, const rt_kd_view *kd, const rt_spath_buffers *b, uint32_t n,
-                          uint32_t random_value)
-{
-    if (!n) return;
-    check_kd(kd, "rt_k_spath_iteration");
-    rt_launch_timer tm(dev, RT_K_SPATH_ITERATION);
-    hipLaunchKernelGGL(k_spath_iteration, dim3(blocks_for(n, 64)), dim3(64), 0, dev->stream,
-                       (const uint2 *)kd->nodes, (const float4 *)kd->leaf_tris, (const float4 *)kd->tri_shade,
-                       (float4 *)b->out_tex, (float4 *)b->ray_o, (float4 *)b->ray_d, (const float4 *)b->origin_o,
-                       (const float4 *)b->origin_d, (Hit *)b->hits, (const Hit *)b->source_hits, (float4 *)b->prog_a,
-                       (float4 *)b->prog_b, (uint32_t *)b->random, n, random_value, host3(kd->scene_min),
-                       host3(kd->scene_max), kd->root_is_leaf);
     RT_AFTER_LAUNCH();
 }
 

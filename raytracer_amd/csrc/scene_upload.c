@@ -111,13 +111,13 @@ void scene_resource_push(raytracer_context *rctx)
     int first_push = (kdt->cl_kd_tree_buffer == NULL);
     if (first_push && kdt->root) {
         kd_tree_flatten(kdt);
-        kdt->cl_kd_tree_buffer = upload_array(rctx, kdt->flat.nodes, sizeof(uint32_t) * 2 * (size_t)kdt->flat.num_nodes);
+        kdt->cl_kd_tree_buffer = upload_array(rctx, kdt->flat.nodes, sizeof(uint32_t) * 4 * (size_t)kdt->flat.num_nodes);
         kdt->view.nodes = kdt->cl_kd_tree_buffer;
         kdt->view.leaf_tris = upload_array(rctx, kdt->flat.leaf_tris, sizeof(float) * 12 * (size_t)kdt->flat.num_leaf_slots);
         kdt->view.num_nodes = kdt->flat.num_nodes;
         kdt->view.num_leaf_slots = kdt->flat.num_leaf_slots;
         kdt->view.num_tris = num_tris;
-        kdt->view.root_is_leaf = kdt->flat.root_is_leaf;
+        kdt->view.root_ref = kdt->flat.root_ref;
         for (int k = 0; k < 3; k++) {
             kdt->view.scene_min[k] = through_percent_f(kdt->bounds.min[k]);
             kdt->view.scene_max[k] = through_percent_f(kdt->bounds.max[k]);

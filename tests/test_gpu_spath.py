@@ -28,7 +28,7 @@ def test_generate_rays_bit_exact(rt, orc, small):
         r.close()
 
 
-@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("fused", [False, True])  # fused = RNG step folded into the shading launch
 def test_spath_state_bit_exact(rt, orc, small, fused):
     sc, tree = small
     w, h, iters, seed = 96, 64, 9, 3
