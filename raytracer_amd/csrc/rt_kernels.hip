@@ -139,9 +139,10 @@ struct Hit { uint32_t tri; float t, u, v; };
 // on an interior node take one descend step, lanes that sit in a leaf test one
 // triangle (and pop when the leaf is used up), and lanes whose ray has finished
 // are handed new rays from a global work counter once enough of them are idle
-// (ballot + prefix rank).  All memory a lane needs for its next step -- the
-// next node, or the next triangle of its leaf -- is requested at the end of the
-// current trip, so a trip costs one memory round trip shared by all 64 lanes.
+// (ballot + prefix rank).  Everything a lane needs for its step -- the node it
+// stands on, or the next triangle of its leaf -- is fetched by all lanes
+// together at the top of the trip, so a trip costs one memory round trip
+// shared by all 64 lanes.
 //
 // Stack entries are {far child, t_split}: an entry's t_max always equals the
 // t_split of the entry below it (scene_t_max for the bottom one), so it is not
@@ -181,13 +182,9 @@ __global__ __launch_bounds__(64) void k_kd_intersect(TravScene P, const float4 *
     f3 o = mk3(0.f, 0.f, 0.f), d = mk3(0.f, 0.f, 0.f);
     float t_min = 0.f, t_max = 0.f, scene_t_max = 0.f, t_hit = RT_INF, hu = 0.f, hv = 0.f;
     uint32_t ref = 0;                       // where the lane stands: interior index or leaf descriptor
-    uint4 node = make_uint4(0, 0, 0, 0);    // the interior node at ref
     uint32_t li = 0, lc = 0, slot = 0;      // leaf progress: triangle li of lc, first slot
-    float4 T0 = make_float4(0, 0, 0, 0), T1 = T0, T2 = T0;   // triangle li of the leaf
 
     for (;;) {
-        bool entered = false;               // lane moved to a new ref this trip: fetch what stands there
-
         // ---- hand new rays to idle lanes -----------------------------------
         const unsigned long long idle = __ballot(!active);
         const uint32_t nidle = (uint32_t)__popcll(idle);
@@ -222,7 +219,7 @@ __global__ __launch_bounds__(64) void k_kd_intersect(TravScene P, const float4 *
                     if (t_max < scene_t_max) {          // first pass of the reference's outer loop: start at the root
                         t_min = t_max; t_max = scene_t_max;
                         ref = P.root_ref;
-                        entered = true;
+                        lc = RT_REF_COUNT(ref); slot = ref & RT_REF_SLOT_MASK; li = 0;
                         active = true;
                     } else {
                         Hit miss; miss.tri = 0; miss.t = 0.f; miss.u = 0.f; miss.v = 0.f;
@@ -237,10 +234,27 @@ __global__ __launch_bounds__(64) void k_kd_intersect(TravScene P, const float4 *
             continue;
         }
 
+        // ---- fetch what every lane stands on ----------------------------------
+        // Issued by all lanes outside any divergent branch (lanes with nothing to
+        // fetch read element 0, one shared cache line), so the wave pays a single
+        // memory round trip per trip of the loop.
+        const bool at_leaf = (ref & RT_REF_LEAF) != 0;
+        const uint32_t nidx = (active && !at_leaf) ? ref : 0u;
+        const uint32_t tslot = (active && at_leaf && li < lc) ? slot + li : 0u;
+        uint4 node = P.nodes[nidx];
+        const float4 *tp = P.leaf_tris + 3 * (size_t)tslot;
+        float4 T0 = tp[0], T1 = tp[1], T2 = tp[2];
+        // Pin the four loads here: left alone, the compiler sinks each one into
+        // the branch that uses it and the wave then waits for memory twice per trip.
+        asm volatile("" : "+v"(node.x), "+v"(node.y), "+v"(node.z), "+v"(node.w),
+                          "+v"(T0.x), "+v"(T0.y), "+v"(T0.z), "+v"(T0.w),
+                          "+v"(T1.x), "+v"(T1.y), "+v"(T1.z), "+v"(T1.w),
+                          "+v"(T2.x), "+v"(T2.y), "+v"(T2.z));
+
         // ---- one step per lane ----------------------------------------------
-        if (active && !entered) {
-            bool finished = false;
-            if (!(ref & RT_REF_LEAF)) {
+        if (active) {
+            bool finished = false, moved = false;
+            if (!at_leaf) {
                 // descend, reference: src/kernels/kdtree.cl:229-260.  get_elem (:67-75)
                 // adds the masked-out zeros, which turns -0 into +0.
                 const uint32_t k = node.y;
@@ -261,7 +275,7 @@ __global__ __launch_bounds__(64) void k_kd_intersect(TravScene P, const float4 *
                     sp++;
                     t_max = t_split;
                 }
-                entered = true;
+                moved = true;
             } else {
                 // leaf, reference: src/kernels/kdtree.cl:263-302
                 if (li < lc) {
@@ -274,17 +288,13 @@ __global__ __launch_bounds__(64) void k_kd_intersect(TravScene P, const float4 *
                         }
                     }
                     li++;
-                    if (!finished && li < lc) {
-                        const float4 *tp = P.leaf_tris + 3 * (size_t)(slot + li);
-                        T0 = tp[0]; T1 = tp[1]; T2 = tp[2];
-                    }
                 }
                 if (!finished && li >= lc) {
                     // leaf used up: the reference's outer loop test, then restart or pop
                     if ((P.root_ref & RT_REF_LEAF) || !(t_max < scene_t_max)) finished = true;
                     else if (sp == 0) {
                         ref = P.root_ref; t_min = t_max; t_max = scene_t_max;
-                        entered = true;
+                        moved = true;
                     } else {
                         sp--;
                         const uint2 e = (sp < (uint32_t)LDS_DEPTH) ? col[sp * 64] : spill[sp - LDS_DEPTH];
@@ -295,7 +305,7 @@ __global__ __launch_bounds__(64) void k_kd_intersect(TravScene P, const float4 *
                             const uint2 below = (sp - 1 < (uint32_t)LDS_DEPTH) ? col[(sp - 1) * 64] : spill[sp - 1 - LDS_DEPTH];
                             t_max = __uint_as_float(below.y);
                         }
-                        entered = true;
+                        moved = true;
                     }
                 }
             }
@@ -305,22 +315,8 @@ __global__ __launch_bounds__(64) void k_kd_intersect(TravScene P, const float4 *
                 else { h.tri = 0; h.t = 0.f; h.u = 0.f; h.v = 0.f; }
                 hits[ridx] = h;
                 active = false;
-                entered = false;
-            }
-        }
-
-        // ---- request what stands at the lane's new position -------------------
-        if (active && entered) {
-            if (!(ref & RT_REF_LEAF)) {
-                node = P.nodes[ref];
-            } else {
-                lc = RT_REF_COUNT(ref);
-                slot = ref & RT_REF_SLOT_MASK;
-                li = 0;
-                if (lc) {
-                    const float4 *tp = P.leaf_tris + 3 * (size_t)slot;
-                    T0 = tp[0]; T1 = tp[1]; T2 = tp[2];
-                }
+            } else if (moved) {
+                lc = RT_REF_COUNT(ref); slot = ref & RT_REF_SLOT_MASK; li = 0;   // meaningful when ref is a leaf
             }
         }
     }

@@ -113,7 +113,11 @@ void scene_resource_push(raytracer_context *rctx)
         kd_tree_flatten(kdt);
         kdt->cl_kd_tree_buffer = upload_array(rctx, kdt->flat.nodes, sizeof(uint32_t) * 4 * (size_t)kdt->flat.num_nodes);
         kdt->view.nodes = kdt->cl_kd_tree_buffer;
-        kdt->view.leaf_tris = upload_array(rctx, kdt->flat.leaf_tris, sizeof(float) * 12 * (size_t)kdt->flat.num_leaf_slots);
+        /* the kernels may read slot 0 / node 0 as a harmless dummy: keep both allocated */
+        kdt->view.leaf_tris = rt_mem_alloc(dev, sizeof(float) * 12 * ((size_t)kdt->flat.num_leaf_slots + 1));
+        rt_mem_zero(dev, kdt->view.leaf_tris, sizeof(float) * 12 * ((size_t)kdt->flat.num_leaf_slots + 1));
+        if (kdt->flat.num_leaf_slots)
+            rt_mem_upload(dev, kdt->view.leaf_tris, kdt->flat.leaf_tris, sizeof(float) * 12 * (size_t)kdt->flat.num_leaf_slots);
         kdt->view.num_nodes = kdt->flat.num_nodes;
         kdt->view.num_leaf_slots = kdt->flat.num_leaf_slots;
         kdt->view.num_tris = num_tris;
