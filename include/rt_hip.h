@@ -42,7 +42,15 @@ rt_device *rt_device_open(int ordinal);                 /* create_context */
 void       rt_device_close(rt_device *dev);
 void       rt_device_get_props(rt_device *dev, rt_device_props *out);   /* cl_info */
 void       rt_device_sync(rt_device *dev);              /* clFinish */
-void      *rt_device_stream(rt_device *dev);            /* hipStream_t, for callers that record their own events */
+void      *rt_device_stream(rt_device *dev);            /* current hipStream_t, for callers that record their own events */
+/* A device owns RT_MAX_STREAMS in-order streams.  Launches, zero-fills and
+   copies go to the selected one (0 after rt_device_open); work on different
+   streams may overlap on the GPU and is unordered until rt_device_sync, which
+   waits for all of them.  Independent pixel ranges of one frame are rendered
+   on different streams so that the long tail of one range's traversal overlaps
+   the bulk of the next. */
+#define RT_MAX_STREAMS 8
+void       rt_device_select_stream(rt_device *dev, int index);
 int        rt_device_ordinal(rt_device *dev);
 
 rt_mem rt_mem_alloc(rt_device *dev, size_t bytes);      /* clCreateBuffer */

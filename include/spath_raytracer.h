@@ -47,6 +47,7 @@ typedef struct spath_raytracer_context {
     unsigned int resolve_interval;    /* resolve + readback every this many iterations (reference: 50) */
     int          separate_kernels;    /* 1: three launches per iteration as the reference; 0: RNG step folded into shading */
     bool         quiet;
+    unsigned int num_segments;        /* the frame is rendered as this many independent pixel ranges, one stream each (1..RT_MAX_STREAMS) */
 } spath_raytracer_context;
 
 spath_raytracer_context *init_spath_raytracer_context(struct _rt_ctx *rctx);   /* src/spath_raytracer.c:39-116 */

@@ -132,6 +132,14 @@ class KdTree:
                                C.byref(st) if stats else None, C.c_int(nthreads or max_threads()))
         return (out, st.as_dict()) if stats else out
 
+    def ray_steps(self, rays: np.ndarray, nthreads: int = 0) -> np.ndarray:
+        """[n, 2] array: interior nodes visited and triangles tested per ray."""
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
+        steps = np.zeros((rays.shape[0], 2), np.uint32)
+        lib().orc_kd_ray_steps(_p(self.blob), _p(self.idx4), _p(self.verts4), _p(rays), C.c_uint32(rays.shape[0]),
+                               _p(self.scene_min), _p(self.scene_max), _p(steps), C.c_int(nthreads or max_threads()))
+        return steps
+
 
 def ref_kd_blob(verts4: np.ndarray, idx4: np.ndarray):
     """(blob bytes, counts5, bounds6) from the reference's own builder."""

@@ -623,6 +623,25 @@ ORC_API void orc_kd_intersect(const uint8_t *blob, const int32_t *idx4, const fl
     if (stats) *stats = total;
 }
 
+/* per-ray work profile: steps[2*i] = interior nodes visited, steps[2*i+1] = triangles tested */
+ORC_API void orc_kd_ray_steps(const uint8_t *blob, const int32_t *idx4, const float *verts4,
+                              const float *rays, uint32_t n, const float *smin3, const float *smax3,
+                              uint32_t *steps, int nthreads)
+{
+    v3 smin = v3_ld(smin3), smax = v3_ld(smax3);
+#ifdef _OPENMP
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for schedule(dynamic, 1024) num_threads(nthreads)
+#endif
+    for (int64_t i = 0; i < (int64_t)n; i++) {
+        orc_kd_stats st;
+        memset(&st, 0, sizeof st);
+        (void)kd_trace_one(blob, idx4, verts4, rays + 8 * i, smin, smax, &st);
+        steps[2 * i] = (uint32_t)st.nodes_visited;
+        steps[2 * i + 1] = (uint32_t)st.tri_tests;
+    }
+}
+
 /* exact nearest-hit brute force over every triangle (same Moeller-Trumbore);
    used by property tests, not a restatement of any reference function */
 ORC_API void orc_brute_nearest(const int32_t *idx4, const float *verts4, uint32_t nidx,

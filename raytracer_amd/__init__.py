@@ -127,7 +127,7 @@ class spath_raytracer_context(C.Structure):
                 ("cl_bad_api_design_buffer", C.c_void_p), ("cl_path_ray_origin_dir_buffer", C.c_void_p),
                 ("cl_spath_progress_b_buffer", C.c_void_p), ("rng_mode", C.c_int), ("rng_seed", C.c_uint),
                 ("rng_launch", C.c_uint), ("resolve_interval", C.c_uint), ("separate_kernels", C.c_int),
-                ("quiet", C.c_bool)]
+                ("quiet", C.c_bool), ("num_segments", C.c_uint)]
 
 
 class rt_device_props(C.Structure):
@@ -147,14 +147,14 @@ _ABI_OFFSETS = [("raytracer_context", "stat_scene"), ("raytracer_context", "rcl"
                 ("scene", "kdt"), ("scene", "mesh_indices"), ("scene", "num_mesh_indices"),
                 ("kd_tree", "bounds"), ("kd_tree", "buffer"), ("kd_tree", "flat"), ("kd_tree", "view"),
                 ("kd_tree", "build_threads"), ("spath_raytracer_context", "cl_random_buffer"),
-                ("spath_raytracer_context", "rng_mode"), ("spath_raytracer_context", "quiet"),
+                ("spath_raytracer_context", "rng_mode"), ("spath_raytracer_context", "quiet"), ("spath_raytracer_context", "num_segments"),
                 ("path_raytracer_context", "cl_path_output_buffer")]
 
 # every symbol the headers under include/ declare
 EXPORTED_SYMBOLS = [
     # rt_hip.h
     "rt_device_count", "rt_device_open", "rt_device_close", "rt_device_get_props", "rt_device_sync",
-    "rt_device_stream", "rt_device_ordinal", "rt_mem_alloc", "rt_mem_free", "rt_mem_upload", "rt_mem_download",
+    "rt_device_stream", "rt_device_ordinal", "rt_device_select_stream", "rt_mem_alloc", "rt_mem_free", "rt_mem_upload", "rt_mem_download",
     "rt_mem_zero", "rt_mem_copy", "rt_timing_enable", "rt_timing_reset", "rt_timing_get", "rt_kernel_name",
     "rt_k_generate_rays", "rt_k_kd_intersect", "rt_k_spath_init", "rt_k_spath_trace", "rt_k_xorshift",
     "rt_k_resolve_avg", "rt_k_cast_rays", "rt_k_path_trace", "rt_k_f_buffer_average",
@@ -224,6 +224,7 @@ def lib():
     L.rt_device_get_props.argtypes = [vp, C.POINTER(rt_device_props)]
     L.rt_device_sync.argtypes = [vp]
     L.rt_device_stream.restype = vp; L.rt_device_stream.argtypes = [vp]
+    L.rt_device_select_stream.argtypes = [vp, C.c_int]
     L.rt_mem_alloc.restype = vp; L.rt_mem_alloc.argtypes = [vp, C.c_size_t]
     L.rt_mem_free.argtypes = [vp, vp]
     L.rt_mem_upload.argtypes = [vp, vp, vp, C.c_size_t]
@@ -365,7 +366,8 @@ class Renderer:
     def kdt(self):
         return self.scene.contents.kdt.contents
 
-    def init_spath(self, seed: int = 1, separate_kernels: bool = False, resolve_interval: int = 50, quiet: bool = True):
+    def init_spath(self, seed: int = 1, separate_kernels: bool = False, resolve_interval: int = 50, quiet: bool = True,
+                   segments: int | None = None):
         if not self.built:
             self.build()
         self.spath = self.L.init_spath_raytracer_context(self.rctx)
@@ -375,6 +377,8 @@ class Renderer:
         c.separate_kernels = 1 if separate_kernels else 0
         c.resolve_interval = resolve_interval
         c.quiet = quiet
+        if segments is not None:
+            c.num_segments = segments
         return self.spath
 
     def spath_prepass(self, num_iterations: int | None = None):

@@ -71,6 +71,7 @@ spath_raytracer_context *init_spath_raytracer_context(struct _rt_ctx *rctx)
     c->resolve_interval = 50;        /* reference: src/spath_raytracer.c:389-390 */
     c->separate_kernels = 0;
     c->quiet = false;
+    c->num_segments = 4;
     return c;
 }
 
@@ -93,6 +94,7 @@ void spath_raytracer_resolve(spath_raytracer_context *c)
 {
     raytracer_context *rctx = c->rctx;
     const unsigned int n = rctx->width * rctx->height;
+    rt_device_sync(rctx->rcl->device);           /* every pixel range's stream */
     rt_k_resolve_avg(rctx->rcl->device, rctx->cl_output_buffer, c->cl_path_output_buffer, n);
     rt_mem_download(rctx->rcl->device, rctx->output_buffer, rctx->cl_output_buffer, (size_t)n * 4);
 }
@@ -151,6 +153,7 @@ void spath_raytracer_render(spath_raytracer_context *c)
     c->current_iteration++;
     if (c->current_iteration > c->num_iterations) {
         /* the reference still steps the RNG buffer on this call (src/spath_raytracer.c:364-373) */
+        rt_device_sync(dev);
         rt_k_xorshift(dev, b.random, n);
         if (!c->render_complete) {
             spath_raytracer_resolve(c);
@@ -160,15 +163,30 @@ void spath_raytracer_render(spath_raytracer_context *c)
         return;
     }
 
+    /* Pixels are independent, so the frame is cut into num_segments ranges and
+       each range's launches go to a stream of its own: while the last, longest
+       rays of one range finish, the next range's traversal already fills the
+       GPU.  Within a stream the order xorshift -> traversal -> shading of the
+       reference is kept. */
     const uint32_t rv = next_random_value(c);
-    if (c->separate_kernels) {
-        rt_k_xorshift(dev, b.random, n);
-        rt_k_kd_intersect(dev, &kdt->view, b.ray_o, b.ray_d, b.hits, n);
-        rt_k_spath_trace(dev, &kdt->view, &b, n, rv, 0);
-    } else {
-        rt_k_kd_intersect(dev, &kdt->view, b.ray_o, b.ray_d, b.hits, n);
-        rt_k_spath_trace(dev, &kdt->view, &b, n, rv, 1);      /* RNG step folded into the shading launch */
+    unsigned int segs = c->num_segments ? c->num_segments : 1;
+    if (segs > RT_MAX_STREAMS) segs = RT_MAX_STREAMS;
+    if (segs > n / 4096u + 1u) segs = n / 4096u + 1u;
+    for (unsigned int s = 0; s < segs; s++) {
+        const unsigned int lo = (unsigned int)((unsigned long long)n * s / segs);
+        const unsigned int hi = (unsigned int)((unsigned long long)n * (s + 1) / segs);
+        rt_spath_buffers sb;
+        sb.ray_o = (char *)b.ray_o + 16ull * lo;       sb.ray_d = (char *)b.ray_d + 16ull * lo;
+        sb.origin_o = (char *)b.origin_o + 16ull * lo; sb.origin_d = (char *)b.origin_d + 16ull * lo;
+        sb.hits = (char *)b.hits + 16ull * lo;         sb.source_hits = (char *)b.source_hits + 16ull * lo;
+        sb.prog_a = (char *)b.prog_a + 16ull * lo;     sb.prog_b = (char *)b.prog_b + 16ull * lo;
+        sb.random = (char *)b.random + 4ull * lo;      sb.out_tex = (char *)b.out_tex + 16ull * lo;
+        rt_device_select_stream(dev, (int)s);
+        if (c->separate_kernels) rt_k_xorshift(dev, sb.random, hi - lo);
+        rt_k_kd_intersect(dev, &kdt->view, sb.ray_o, sb.ray_d, sb.hits, hi - lo);
+        rt_k_spath_trace(dev, &kdt->view, &sb, hi - lo, rv, c->separate_kernels ? 0 : 1);
     }
+    rt_device_select_stream(dev, 0);
 
     if (c->resolve_interval && c->current_iteration % c->resolve_interval == 0) {
         spath_raytracer_resolve(c);

@@ -31,9 +31,13 @@ rt_device *rt_device_open(int ordinal)
     dev->ordinal = ordinal;
     RT_HIP_CHECK(hipSetDevice(ordinal));
     RT_HIP_CHECK(hipGetDeviceProperties(&dev->props, ordinal));
-    RT_HIP_CHECK(hipStreamCreateWithFlags(&dev->stream, hipStreamNonBlocking));
-    RT_HIP_CHECK(hipMalloc((void **)&dev->counters, 256));
-    RT_HIP_CHECK(hipMemset(dev->counters, 0, 256));
+    dev->num_streams = RT_MAX_STREAMS;
+    for (int i = 0; i < dev->num_streams; i++)
+        RT_HIP_CHECK(hipStreamCreateWithFlags(&dev->streams[i], hipStreamNonBlocking));
+    dev->current = 0;
+    dev->stream = dev->streams[0];
+    RT_HIP_CHECK(hipMalloc((void **)&dev->counters, 64 * RT_MAX_STREAMS));
+    RT_HIP_CHECK(hipMemset(dev->counters, 0, 64 * RT_MAX_STREAMS));
     return dev;
 }
 
@@ -41,13 +45,13 @@ void rt_device_close(rt_device *dev)
 {
     if (!dev) return;
     RT_HIP_CHECK(hipSetDevice(dev->ordinal));
-    RT_HIP_CHECK(hipStreamSynchronize(dev->stream));
+    rt_device_sync(dev);
     for (int k = 0; k < RT_K_COUNT; k++) {
         for (hipEvent_t e : dev->slots[k].start) (void)hipEventDestroy(e);
         for (hipEvent_t e : dev->slots[k].stop) (void)hipEventDestroy(e);
     }
     for (hipEvent_t e : dev->free_events) (void)hipEventDestroy(e);
-    RT_HIP_CHECK(hipStreamDestroy(dev->stream));
+    for (int i = 0; i < dev->num_streams; i++) RT_HIP_CHECK(hipStreamDestroy(dev->streams[i]));
     RT_HIP_CHECK(hipFree(dev->counters));
     delete dev;
 }
@@ -65,7 +69,17 @@ void rt_device_get_props(rt_device *dev, rt_device_props *out)
 
 void rt_device_sync(rt_device *dev)
 {
-    RT_HIP_CHECK(hipStreamSynchronize(dev->stream));
+    for (int i = 0; i < dev->num_streams; i++) RT_HIP_CHECK(hipStreamSynchronize(dev->streams[i]));
+}
+
+void rt_device_select_stream(rt_device *dev, int index)
+{
+    if (index < 0 || index >= dev->num_streams) {
+        fprintf(stderr, "ERROR: stream index %d out of range (%d streams)\n", index, dev->num_streams);
+        exit(1);
+    }
+    dev->current = index;
+    dev->stream = dev->streams[index];
 }
 
 void *rt_device_stream(rt_device *dev) { return (void *)dev->stream; }
@@ -83,13 +97,14 @@ void rt_mem_free(rt_device *dev, rt_mem m)
 {
     if (!m) return;
     RT_HIP_CHECK(hipSetDevice(dev->ordinal));
-    RT_HIP_CHECK(hipStreamSynchronize(dev->stream));
+    rt_device_sync(dev);
     RT_HIP_CHECK(hipFree(m));
 }
 
 void rt_mem_upload(rt_device *dev, rt_mem dst, const void *src, size_t bytes)
 {
     if (!bytes) return;
+    rt_device_sync(dev);       /* blocking transfer: ordered behind everything queued on any stream */
     RT_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, dev->stream));
     RT_HIP_CHECK(hipStreamSynchronize(dev->stream));
 }
@@ -97,6 +112,7 @@ void rt_mem_upload(rt_device *dev, rt_mem dst, const void *src, size_t bytes)
 void rt_mem_download(rt_device *dev, void *dst, rt_mem src, size_t bytes)
 {
     if (!bytes) return;
+    rt_device_sync(dev);
     RT_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, dev->stream));
     RT_HIP_CHECK(hipStreamSynchronize(dev->stream));
 }
@@ -117,7 +133,7 @@ void rt_timing_enable(rt_device *dev, int on) { dev->timing = on ? 1 : 0; }
 
 void rt_timing_reset(rt_device *dev)
 {
-    RT_HIP_CHECK(hipStreamSynchronize(dev->stream));
+    rt_device_sync(dev);
     for (int k = 0; k < RT_K_COUNT; k++) {
         rt_timing_fold(dev, k);
         dev->slots[k].launches = 0;
@@ -128,7 +144,7 @@ void rt_timing_reset(rt_device *dev)
 void rt_timing_get(rt_device *dev, int kernel_id, uint64_t *launches, double *total_ms)
 {
     if (kernel_id < 0 || kernel_id >= RT_K_COUNT) { *launches = 0; *total_ms = 0; return; }
-    RT_HIP_CHECK(hipStreamSynchronize(dev->stream));
+    rt_device_sync(dev);
     rt_timing_fold(dev, kernel_id);
     *launches = dev->slots[kernel_id].launches;
     *total_ms = dev->slots[kernel_id].total_ms;
@@ -174,7 +190,7 @@ rt_launch_timer::rt_launch_timer(rt_device *d, int kernel_id) : dev(d), id(kerne
 {
     if (!dev->timing) return;
     if (dev->slots[id].start.size() >= 16384) {   // bound the number of live events
-        RT_HIP_CHECK(hipStreamSynchronize(dev->stream));
+        rt_device_sync(dev);
         rt_timing_fold(dev, id);
     }
     e0 = take_event(dev);

@@ -30,12 +30,14 @@ struct rt_timing_slot {
 
 struct rt_device {
     int ordinal = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;              // the stream launches currently go to (one of streams[])
+    hipStream_t streams[RT_MAX_STREAMS] = {};
+    int num_streams = 0, current = 0;
     hipDeviceProp_t props;
     int timing = 0;
     rt_timing_slot slots[RT_K_COUNT];
     std::vector<hipEvent_t> free_events;
-    uint32_t *counters = nullptr;   // device words the kernels use as work counters (256 bytes)
+    uint32_t *counters = nullptr;   // device words the kernels use as work counters: one 64-byte line per stream
 };
 
 // Brackets one launch with events when timing is on.

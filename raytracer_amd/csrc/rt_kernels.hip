@@ -782,12 +782,19 @@ void launch_kd_variant(rt_device *dev, const TravScene &P, const float4 *ro, con
         RT_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kern, 64, 0));
         if (blocks_per_cu < 1) blocks_per_cu = 1;
     }
-    unsigned grid = (unsigned)blocks_per_cu * (unsigned)dev->props.multiProcessorCount;
+    static int waves_per_cu = -1;
+    if (waves_per_cu < 0) {
+        const char *e = getenv("RT_TRAVERSE_WAVES_PER_CU");
+        waves_per_cu = e ? atoi(e) : 0;
+    }
+    unsigned per_cu = (waves_per_cu > 0 && waves_per_cu < blocks_per_cu) ? (unsigned)waves_per_cu : (unsigned)blocks_per_cu;
+    unsigned grid = per_cu * (unsigned)dev->props.multiProcessorCount;
     const unsigned need = blocks_for(n, 64);
     if (grid > need) grid = need;
-    RT_HIP_CHECK(hipMemsetAsync(dev->counters, 0, sizeof(uint32_t), dev->stream));
+    uint32_t *counter = dev->counters + 16 * dev->current;     // this stream's own 64-byte line
+    RT_HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(uint32_t), dev->stream));
     rt_launch_timer tm(dev, RT_K_KD_INTERSECT);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, dev->stream, P, ro, rd, hits, n, dev->counters);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, dev->stream, P, ro, rd, hits, n, counter);
     RT_HIP_CHECK(hipGetLastError());
 }
 

@@ -1,0 +1,144 @@
+"""kd-tree builder parity on the CPU: oracle restatement vs the reference's own
+builder (oracle/_ref, where built), product builder vs oracle, and both vs the
+committed golden blob."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _scenes(rt):
+    s = rt.scenes
+    return {"ico2": s.icosphere_scene(2), "ico4": s.icosphere_scene(4), "soup2k": s.soup_scene(2000),
+            "mixed": s.mixed_scene(2)}
+
+
+@pytest.mark.parametrize("name", ["ico2", "ico4", "soup2k", "mixed"])
+def test_oracle_builder_matches_reference_builder(rt, orc, name):
+    if orc.ref_lib() is None:
+        pytest.skip("oracle/_ref not built (no reference checkout here)")
+    sc = _scenes(rt)[name]
+    kt = orc.KdTree(sc.verts4, sc.idx4)
+    blob, counts, bounds = orc.ref_kd_blob(sc.verts4, sc.idx4)
+    assert kt.blob_size == blob.shape[0]
+    assert [kt.counts[k] for k in ("nodes_total", "traversal", "leaves", "indices_total", "tris_padded")] == list(counts)
+    m = orc.blob_significant_mask(kt.blob, kt.blob_used)
+    assert (kt.blob[m] == blob[m]).all()
+    assert np.array_equal(bounds[:3], kt.bounds_min) and np.array_equal(bounds[3:], kt.bounds_max)
+    assert kt.counts["count_mismatch"] == 0
+
+
+def test_reference_obj_mesh_if_present(rt, orc):
+    """One of the reference's own meshes through all three builders (only where
+    the reference checkout and its builder are available)."""
+    path = "/root/reference/res/mesh/test.obj"
+    if orc.ref_lib() is None or not os.path.exists(path):
+        pytest.skip("reference checkout not present")
+    v, vn, f = [], [], []
+    for line in open(path):
+        p = line.split()
+        if not p:
+            continue
+        if p[0] == "v":
+            v.append([float(x) for x in p[1:4]])
+        elif p[0] == "vn":
+            vn.append([float(x) for x in p[1:4]])
+        elif p[0] == "f":
+            idx = [[int(a) if a else 0 for a in (q.split("/") + ["", ""])[:3]] for q in p[1:]]
+            for i in range(1, len(idx) - 1):
+                f.append([idx[0], idx[i], idx[i + 1]])
+    f = np.array(f)
+    sc = rt.scenes._assemble([(np.array(v, np.float32), np.array(vn, np.float32), f[:, :, 0] - 1, f[:, :, 2] - 1, 3)],
+                             rt.scenes._materials(rt.scenes._PATH_MATERIALS))
+    kt = orc.KdTree(sc.verts4, sc.idx4)
+    blob, counts, _ = orc.ref_kd_blob(sc.verts4, sc.idx4)
+    m = orc.blob_significant_mask(kt.blob, kt.blob_used)
+    assert (kt.blob[m] == blob[m]).all()
+    hk = rt.HostKdTree(sc)
+    assert (hk.blob == kt.blob[:kt.blob_size]).all()
+
+
+@pytest.mark.parametrize("name", ["ico2", "ico4", "soup2k", "mixed"])
+@pytest.mark.parametrize("threads", [1, 4])
+def test_product_builder_matches_oracle(rt, orc, name, threads):
+    sc = _scenes(rt)[name]
+    kt = orc.KdTree(sc.verts4, sc.idx4)
+    hk = rt.HostKdTree(sc, threads=threads)
+    assert hk.blob.shape[0] == kt.blob_size
+    assert (hk.blob == kt.blob[:kt.blob_size]).all()
+    for k in ("nodes_total", "traversal", "leaves", "indices_total", "tris_padded"):
+        assert hk.counts[k] == kt.counts[k]
+
+
+def _decode_flat(hk):
+    """Leaves of the flattened tree in depth-first order: list of index-offset tuples."""
+    leaves = []
+
+    def walk(ref):
+        if ref & 0x80000000:
+            cnt, slot = (ref >> 26) & 31, ref & 0x03FFFFFF
+            if cnt == 31:
+                cnt = int(hk.leaf_tris[slot, 7].view(np.uint32))
+            leaves.append(tuple(int(hk.leaf_tris[slot + i, 3].view(np.uint32)) for i in range(cnt)))
+            return
+        n = hk.nodes[ref]
+        walk(int(n[2]))
+        walk(int(n[3]))
+    import sys
+    sys.setrecursionlimit(10000)
+    walk(hk.root_ref)
+    return leaves
+
+
+def _decode_blob(blob):
+    leaves, off = [], 0
+    while off < blob.shape[0]:
+        t = int(blob[off])
+        if t == 2:
+            off += 32
+        elif t == 1:
+            n = int(blob[off + 4:off + 8].view(np.uint32)[0])
+            leaves.append(tuple(int(x) for x in blob[off + 16:off + 16 + 4 * n].view(np.uint32)))
+            off += 16 + 4 * n + (4 if n % 2 else 0)
+        else:
+            break
+    return leaves
+
+
+@pytest.mark.parametrize("name", ["ico4", "soup2k"])
+def test_flattened_tree_has_the_same_leaves_in_the_same_order(rt, orc, name):
+    sc = _scenes(rt)[name]
+    hk = rt.HostKdTree(sc)
+    kt = orc.KdTree(sc.verts4, sc.idx4)
+    assert _decode_flat(hk) == _decode_blob(kt.blob[:kt.blob_used])
+    # precomputed edges are exactly v1-v0, v2-v0
+    off = int(hk.leaf_tris[0, 3].view(np.uint32))
+    a, b, c = (sc.verts4[sc.idx4[off + i, 0], :3] for i in range(3))
+    assert np.array_equal(hk.leaf_tris[0, 0:3], a)
+    assert np.array_equal(hk.leaf_tris[0, 4:7], b - a)
+    assert np.array_equal(hk.leaf_tris[0, 8:11], c - a)
+
+
+def test_single_leaf_tree_and_empty_scene(rt, orc):
+    sc = rt.scenes._assemble([rt.scenes._quad((0, 0, -3), (1, 0, -3), (1, 1, -3), (0, 1, -3), (0, 0, 1)) + (0,)],
+                             rt.scenes._materials(rt.scenes._PATH_MATERIALS))
+    hk = rt.HostKdTree(sc)
+    assert hk.root_ref & 0x80000000 and hk.counts["leaves"] == 1 and hk.counts["traversal"] == 0
+    kt = orc.KdTree(sc.verts4, sc.idx4)
+    assert (hk.blob == kt.blob[:kt.blob_size]).all()
+
+
+def test_golden_blob(rt, orc):
+    """Golden vector: the serialised tree of the ico2 scene as produced by the
+    REFERENCE's builder (tests/golden/make_golden.py wrote it from oracle/_ref)."""
+    g = np.load(os.path.join(GOLDEN, "kd_ico2.npz"))
+    sc = rt.scenes.icosphere_scene(2)
+    assert hashlib.sha256(sc.verts4.tobytes() + sc.idx4.tobytes()).hexdigest() == str(g["scene_sha256"])
+    kt = orc.KdTree(sc.verts4, sc.idx4)
+    m = g["mask"].astype(bool)
+    assert (kt.blob[:kt.blob_size][m] == g["ref_blob"][m]).all()
+    hk = rt.HostKdTree(sc)
+    assert (hk.blob[m] == g["ref_blob"][m]).all()
