@@ -114,7 +114,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--workload", default=os.environ.get("RT_BENCH_WORKLOAD", "c3"), choices=sorted(WORKLOADS))
     ap.add_argument("--separate-kernels", action="store_true", help="three launches per iteration, as the reference")
-    ap.add_argument("--segments", type=int, default=None, help="independent pixel ranges (streams) per frame")
+    ap.add_argument("--max-batch", type=int, default=None, help="most iterations folded into one launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
@@ -149,7 +149,7 @@ def main():
     r.build()
     t_build = time.perf_counter() - t0
     r.init_spath(seed=1, separate_kernels=args.separate_kernels, resolve_interval=50, quiet=True,
-                 segments=args.segments)
+                 max_batch=args.max_batch)
     r.spath_prepass(num_iterations=1 << 30)
     if rank == 0:
         log(f"[bench] {desc}: {sc.num_tris} triangles, scene {t_scene:.1f}s, build {t_build:.1f}s, "

@@ -45,9 +45,13 @@ typedef struct spath_raytracer_context {
     unsigned int rng_seed;
     unsigned int rng_launch;          /* launches drawn so far */
     unsigned int resolve_interval;    /* resolve + readback every this many iterations (reference: 50) */
-    int          separate_kernels;    /* 1: three launches per iteration as the reference; 0: RNG step folded into shading */
+    int          separate_kernels;    /* 1: three launches per iteration, as the reference; 0: iterations are batched
+                                         into multi-iteration launches (rt_k_spath_run) */
     bool         quiet;
-    unsigned int num_segments;        /* the frame is rendered as this many independent pixel ranges, one stream each (1..RT_MAX_STREAMS) */
+    unsigned int max_batch;           /* most iterations folded into one launch (0 = 64); a batch always ends at a resolve point */
+    unsigned int pending;             /* iterations accepted by spath_raytracer_render but not launched yet */
+    unsigned int *pending_values;     /* their random values */
+    rt_mem       cl_random_value_buffer;
 } spath_raytracer_context;
 
 spath_raytracer_context *init_spath_raytracer_context(struct _rt_ctx *rctx);   /* src/spath_raytracer.c:39-116 */
@@ -55,7 +59,8 @@ void spath_raytracer_render(spath_raytracer_context *ctx);                      
 void spath_raytracer_prepass(spath_raytracer_context *ctx);                     /* src/spath_raytracer.c:404-436 */
 
 /* not in the reference */
-void spath_raytracer_resolve(spath_raytracer_context *ctx);   /* resolve + blocking readback into output_buffer */
+void spath_raytracer_flush(spath_raytracer_context *ctx);     /* launch whatever render calls are still pending */
+void spath_raytracer_resolve(spath_raytracer_context *ctx);   /* flush, resolve + blocking readback into output_buffer */
 void spath_raytracer_fill_buffers(spath_raytracer_context *ctx, rt_spath_buffers *out);
 void spath_raytracer_destroy(spath_raytracer_context *ctx);   /* the reference never releases its buffers */
 

@@ -26,7 +26,8 @@ SS_RAYTRACER, PATH_RAYTRACER, SPLIT_PATH_RAYTRACER = 0, 1, 2
 RT_RNG_LIBC, RT_RNG_SPLITMIX = 0, 1
 
 KERNEL_IDS = {"generate_rays": 0, "kd_intersect": 1, "spath_init": 2, "spath_trace": 3, "xorshift": 4,
-              "resolve_avg": 5, "cast_rays": 6, "path_trace": 7, "f_buffer_average": 8, "f_to_byte": 9}
+              "resolve_avg": 5, "cast_rays": 6, "path_trace": 7, "f_buffer_average": 8, "f_to_byte": 9,
+              "spath_run": 10}
 
 HIT_DT = np.dtype([("tri", "<u4"), ("t", "<f4"), ("u", "<f4"), ("v", "<f4")])
 
@@ -127,7 +128,8 @@ class spath_raytracer_context(C.Structure):
                 ("cl_bad_api_design_buffer", C.c_void_p), ("cl_path_ray_origin_dir_buffer", C.c_void_p),
                 ("cl_spath_progress_b_buffer", C.c_void_p), ("rng_mode", C.c_int), ("rng_seed", C.c_uint),
                 ("rng_launch", C.c_uint), ("resolve_interval", C.c_uint), ("separate_kernels", C.c_int),
-                ("quiet", C.c_bool), ("num_segments", C.c_uint)]
+                ("quiet", C.c_bool), ("max_batch", C.c_uint), ("pending", C.c_uint),
+                ("pending_values", C.POINTER(C.c_uint)), ("cl_random_value_buffer", C.c_void_p)]
 
 
 class rt_device_props(C.Structure):
@@ -147,7 +149,8 @@ _ABI_OFFSETS = [("raytracer_context", "stat_scene"), ("raytracer_context", "rcl"
                 ("scene", "kdt"), ("scene", "mesh_indices"), ("scene", "num_mesh_indices"),
                 ("kd_tree", "bounds"), ("kd_tree", "buffer"), ("kd_tree", "flat"), ("kd_tree", "view"),
                 ("kd_tree", "build_threads"), ("spath_raytracer_context", "cl_random_buffer"),
-                ("spath_raytracer_context", "rng_mode"), ("spath_raytracer_context", "quiet"), ("spath_raytracer_context", "num_segments"),
+                ("spath_raytracer_context", "rng_mode"), ("spath_raytracer_context", "quiet"), ("spath_raytracer_context", "max_batch"),
+                ("spath_raytracer_context", "cl_random_value_buffer"),
                 ("path_raytracer_context", "cl_path_output_buffer")]
 
 # every symbol the headers under include/ declare
@@ -157,7 +160,7 @@ EXPORTED_SYMBOLS = [
     "rt_device_stream", "rt_device_ordinal", "rt_device_select_stream", "rt_mem_alloc", "rt_mem_free", "rt_mem_upload", "rt_mem_download",
     "rt_mem_zero", "rt_mem_copy", "rt_timing_enable", "rt_timing_reset", "rt_timing_get", "rt_kernel_name",
     "rt_k_generate_rays", "rt_k_kd_intersect", "rt_k_spath_init", "rt_k_spath_trace", "rt_k_xorshift",
-    "rt_k_resolve_avg", "rt_k_cast_rays", "rt_k_path_trace", "rt_k_f_buffer_average",
+    "rt_k_spath_run", "rt_k_resolve_avg", "rt_k_cast_rays", "rt_k_path_trace", "rt_k_f_buffer_average",
     "rt_k_f_to_byte",
     # parallel.h
     "cl_info", "create_context", "load_program_raw", "load_program_url", "gen_rgb_image", "gen_grayscale_buffer",
@@ -180,7 +183,7 @@ EXPORTED_SYMBOLS = [
     "init_ss_raytracer_context", "ss_raytracer_render", "ss_raytracer_prepass",
     "init_path_raytracer_context", "path_raytracer_render", "path_raytracer_prepass",
     "init_spath_raytracer_context", "spath_raytracer_render", "spath_raytracer_prepass",
-    "spath_raytracer_resolve", "spath_raytracer_fill_buffers",
+    "spath_raytracer_resolve", "spath_raytracer_flush", "spath_raytracer_fill_buffers",
     "ss_raytracer_destroy", "path_raytracer_destroy", "spath_raytracer_destroy",
 ]
 
@@ -240,6 +243,7 @@ def lib():
     L.rt_k_spath_init.argtypes = [vp, C.POINTER(rt_kd_view), C.POINTER(rt_spath_buffers), u32, u32, u32, u32]
     L.rt_k_spath_trace.argtypes = [vp, C.POINTER(rt_kd_view), C.POINTER(rt_spath_buffers), u32, u32, C.c_int]
     L.rt_k_xorshift.argtypes = [vp, vp, u32]
+    L.rt_k_spath_run.argtypes = [vp, C.POINTER(rt_kd_view), C.POINTER(rt_spath_buffers), u32, u32, vp]
     L.rt_k_resolve_avg.argtypes = [vp, vp, vp, u32]
     L.rt_k_f_buffer_average.argtypes = [vp, vp, vp, u32, u32]
     L.rt_k_f_to_byte.argtypes = [vp, vp, vp, u32]
@@ -270,7 +274,7 @@ def lib():
     L.path_raytracer_prepass.argtypes = [C.POINTER(path_raytracer_context)]
     L.init_spath_raytracer_context.restype = C.POINTER(spath_raytracer_context)
     L.init_spath_raytracer_context.argtypes = [C.POINTER(raytracer_context)]
-    for f in ("spath_raytracer_render", "spath_raytracer_prepass", "spath_raytracer_resolve"):
+    for f in ("spath_raytracer_render", "spath_raytracer_prepass", "spath_raytracer_resolve", "spath_raytracer_flush"):
         getattr(L, f).argtypes = [C.POINTER(spath_raytracer_context)]
     L.spath_raytracer_fill_buffers.argtypes = [C.POINTER(spath_raytracer_context), C.POINTER(rt_spath_buffers)]
     L.spath_raytracer_destroy.argtypes = [C.POINTER(spath_raytracer_context)]
@@ -367,7 +371,7 @@ class Renderer:
         return self.scene.contents.kdt.contents
 
     def init_spath(self, seed: int = 1, separate_kernels: bool = False, resolve_interval: int = 50, quiet: bool = True,
-                   segments: int | None = None):
+                   max_batch: int | None = None):
         if not self.built:
             self.build()
         self.spath = self.L.init_spath_raytracer_context(self.rctx)
@@ -377,8 +381,8 @@ class Renderer:
         c.separate_kernels = 1 if separate_kernels else 0
         c.resolve_interval = resolve_interval
         c.quiet = quiet
-        if segments is not None:
-            c.num_segments = segments
+        if max_batch is not None:
+            c.max_batch = max_batch
         return self.spath
 
     def spath_prepass(self, num_iterations: int | None = None):
@@ -386,10 +390,14 @@ class Renderer:
         if num_iterations is not None:
             self.spath.contents.num_iterations = num_iterations
 
-    def spath_render(self, calls: int = 1):
+    def spath_render(self, calls: int = 1, flush: bool = True):
+        """`calls` render calls; by default the iterations still pending in the
+        library's batch are launched before returning (not waited for)."""
         f = self.L.spath_raytracer_render
         for _ in range(calls):
             f(self.spath)
+        if flush:
+            self.L.spath_raytracer_flush(self.spath)
 
     def spath_resolve(self) -> np.ndarray:
         self.L.spath_raytracer_resolve(self.spath)

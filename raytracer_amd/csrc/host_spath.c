@@ -3,10 +3,12 @@
  * pixel's path per render call.  reference: src/spath_raytracer.c:15-436.
  *
  * The reference synchronises the host after each of its three launches per
- * iteration and rewrites a small buffer in between; here an iteration is queued
- * without waiting (two launches by default: traversal, then shading with the
- * RNG step folded in) and the host only blocks when the frame is resolved and
- * read back, every resolve_interval iterations and at completion.
+ * iteration.  Nothing outside this library can see the per-pixel buffers
+ * between two resolves, so render calls are only recorded (iteration counter,
+ * the call's random value) and launched in batches: one rt_k_spath_run launch
+ * covers every pending iteration, ending at the latest at the next resolve
+ * point, where the frame is resolved and read back exactly when the reference
+ * would have done it.
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -71,7 +73,10 @@ spath_raytracer_context *init_spath_raytracer_context(struct _rt_ctx *rctx)
     c->resolve_interval = 50;        /* reference: src/spath_raytracer.c:389-390 */
     c->separate_kernels = 0;
     c->quiet = false;
-    c->num_segments = 4;
+    c->max_batch = 64;
+    c->pending = 0;
+    c->pending_values = (unsigned int *)malloc(sizeof(unsigned int) * 1024);
+    c->cl_random_value_buffer = rt_mem_alloc(dev, sizeof(unsigned int) * 1024);
     return c;
 }
 
@@ -90,11 +95,27 @@ static void upload_random_buffer(spath_raytracer_context *c)
 }
 
 /* f_buffer_to_byte_buffer_avg + blocking readback, reference: src/spath_raytracer.c:252-277 */
+/* Launches the iterations recorded since the last flush as one batch. */
+void spath_raytracer_flush(spath_raytracer_context *c)
+{
+    if (!c->pending) return;
+    raytracer_context *rctx = c->rctx;
+    rt_device *dev = rctx->rcl->device;
+    const unsigned int n = rctx->width * rctx->height;
+    rt_spath_buffers b;
+    spath_raytracer_fill_buffers(c, &b);
+    /* blocking upload: also orders this batch behind the previous one, so the
+       table is not overwritten while a launch still reads it */
+    rt_mem_upload(dev, c->cl_random_value_buffer, c->pending_values, sizeof(unsigned int) * c->pending);
+    rt_k_spath_run(dev, &rctx->stat_scene->kdt->view, &b, n, c->pending, c->cl_random_value_buffer);
+    c->pending = 0;
+}
+
 void spath_raytracer_resolve(spath_raytracer_context *c)
 {
     raytracer_context *rctx = c->rctx;
     const unsigned int n = rctx->width * rctx->height;
-    rt_device_sync(rctx->rcl->device);           /* every pixel range's stream */
+    spath_raytracer_flush(c);
     rt_k_resolve_avg(rctx->rcl->device, rctx->cl_output_buffer, c->cl_path_output_buffer, n);
     rt_mem_download(rctx->rcl->device, rctx->output_buffer, rctx->cl_output_buffer, (size_t)n * 4);
 }
@@ -110,6 +131,7 @@ void spath_raytracer_prepass(spath_raytracer_context *c)
     c->render_complete = false;
     c->num_iterations = 2048 * 4;
     c->rng_launch = 0;
+    c->pending = 0;
     if (c->rng_mode == RT_RNG_LIBC) srand((unsigned int)rt_time_ms());
     c->start_time = rt_time_ms();
 
@@ -153,7 +175,7 @@ void spath_raytracer_render(spath_raytracer_context *c)
     c->current_iteration++;
     if (c->current_iteration > c->num_iterations) {
         /* the reference still steps the RNG buffer on this call (src/spath_raytracer.c:364-373) */
-        rt_device_sync(dev);
+        spath_raytracer_flush(c);
         rt_k_xorshift(dev, b.random, n);
         if (!c->render_complete) {
             spath_raytracer_resolve(c);
@@ -163,30 +185,17 @@ void spath_raytracer_render(spath_raytracer_context *c)
         return;
     }
 
-    /* Pixels are independent, so the frame is cut into num_segments ranges and
-       each range's launches go to a stream of its own: while the last, longest
-       rays of one range finish, the next range's traversal already fills the
-       GPU.  Within a stream the order xorshift -> traversal -> shading of the
-       reference is kept. */
     const uint32_t rv = next_random_value(c);
-    unsigned int segs = c->num_segments ? c->num_segments : 1;
-    if (segs > RT_MAX_STREAMS) segs = RT_MAX_STREAMS;
-    if (segs > n / 4096u + 1u) segs = n / 4096u + 1u;
-    for (unsigned int s = 0; s < segs; s++) {
-        const unsigned int lo = (unsigned int)((unsigned long long)n * s / segs);
-        const unsigned int hi = (unsigned int)((unsigned long long)n * (s + 1) / segs);
-        rt_spath_buffers sb;
-        sb.ray_o = (char *)b.ray_o + 16ull * lo;       sb.ray_d = (char *)b.ray_d + 16ull * lo;
-        sb.origin_o = (char *)b.origin_o + 16ull * lo; sb.origin_d = (char *)b.origin_d + 16ull * lo;
-        sb.hits = (char *)b.hits + 16ull * lo;         sb.source_hits = (char *)b.source_hits + 16ull * lo;
-        sb.prog_a = (char *)b.prog_a + 16ull * lo;     sb.prog_b = (char *)b.prog_b + 16ull * lo;
-        sb.random = (char *)b.random + 4ull * lo;      sb.out_tex = (char *)b.out_tex + 16ull * lo;
-        rt_device_select_stream(dev, (int)s);
-        if (c->separate_kernels) rt_k_xorshift(dev, sb.random, hi - lo);
-        rt_k_kd_intersect(dev, &kdt->view, sb.ray_o, sb.ray_d, sb.hits, hi - lo);
-        rt_k_spath_trace(dev, &kdt->view, &sb, hi - lo, rv, c->separate_kernels ? 0 : 1);
+    if (c->separate_kernels) {
+        rt_k_xorshift(dev, b.random, n);
+        rt_k_kd_intersect(dev, &kdt->view, b.ray_o, b.ray_d, b.hits, n);
+        rt_k_spath_trace(dev, &kdt->view, &b, n, rv, 0);
+    } else {
+        unsigned int cap = c->max_batch ? c->max_batch : 64;
+        if (cap > 1024) cap = 1024;
+        c->pending_values[c->pending++] = rv;
+        if (c->pending >= cap || c->current_iteration == c->num_iterations) spath_raytracer_flush(c);
     }
-    rt_device_select_stream(dev, 0);
 
     if (c->resolve_interval && c->current_iteration % c->resolve_interval == 0) {
         spath_raytracer_resolve(c);
@@ -208,6 +217,8 @@ void spath_raytracer_destroy(spath_raytracer_context *c)
     rt_mem_free(dev, c->cl_random_buffer);
     rt_mem_free(dev, c->cl_spath_progress_buffer);
     rt_mem_free(dev, c->cl_spath_progress_b_buffer);
+    rt_mem_free(dev, c->cl_random_value_buffer);
+    free(c->pending_values);
     free(c->random_buffer);
     free(c);
 }

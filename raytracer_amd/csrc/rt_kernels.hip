@@ -162,6 +162,165 @@ struct TravScene {
     uint32_t root_ref;
 };
 
+// Registers of one lane's walk.
+struct Walk {
+    f3 o, d;
+    float t_min, t_max, scene_t_max, t_hit, hu, hv;
+    uint32_t tri_indx, sp;
+    uint32_t ref;            // where the lane stands: interior index or leaf descriptor
+    uint32_t li, lc, slot;   // leaf progress: triangle li of lc, first slot
+};
+
+__device__ __forceinline__ void walk_enter(Walk &w, uint32_t ref)
+{
+    w.ref = ref;
+    w.lc = RT_REF_COUNT(ref); w.slot = ref & RT_REF_SLOT_MASK; w.li = 0;   // meaningful when ref is a leaf
+}
+
+// Start a ray (w.o, w.d set by the caller): slab clip against the scene box
+// (getTBoundingBox, reference: src/kernels/collision.cl:71-86) and the first
+// pass of the reference's outer loop.  false = the walk is over before it
+// starts (the ray misses the box): the result is a miss.
+__device__ __forceinline__ bool walk_begin(const TravScene &P, Walk &w)
+{
+    float scene_t_min = 0.f;
+    w.scene_t_max = RT_INF;
+    f3 inv = mk3(1 / w.d.x, 1 / w.d.y, 1 / w.d.z);
+    f3 t0 = (P.smin - w.o) * inv, t1 = (P.smax - w.o) * inv;
+    f3 sm = mk3(cl_min(t0.x, t1.x), cl_min(t0.y, t1.y), cl_min(t0.z, t1.z));
+    f3 bg = mk3(cl_max(t0.x, t1.x), cl_max(t0.y, t1.y), cl_max(t0.z, t1.z));
+    scene_t_min = cl_max(scene_t_min, cl_max(sm.x, cl_max(sm.y, sm.z)));
+    w.scene_t_max = cl_min(w.scene_t_max, cl_min(bg.x, cl_min(bg.y, bg.z)));
+    if (!(scene_t_min < w.scene_t_max)) w.scene_t_max = -RT_INF;
+    w.t_hit = RT_INF; w.hu = 0.f; w.hv = 0.f; w.tri_indx = 0; w.sp = 0;
+    w.t_min = w.t_max = scene_t_min;
+    if (!(w.t_max < w.scene_t_max)) return false;
+    w.t_min = w.t_max; w.t_max = w.scene_t_max;     // restart at the root (kdtree.cl:208-216)
+    walk_enter(w, P.root_ref);
+    return true;
+}
+
+// Fetch what every lane stands on.  Issued by all lanes outside any divergent
+// branch (lanes with nothing to fetch read element 0, one shared cache line)
+// and pinned with an empty asm: left alone, the compiler sinks each load into
+// the branch that uses it and the wave then waits for memory twice per trip.
+__device__ __forceinline__ void walk_fetch(const TravScene &P, const Walk &w, bool walking, uint4 &node, float4 &T0,
+                                           float4 &T1, float4 &T2)
+{
+    const bool at_leaf = (w.ref & RT_REF_LEAF) != 0;
+    const uint32_t nidx = (walking && !at_leaf) ? w.ref : 0u;
+    const uint32_t tslot = (walking && at_leaf && w.li < w.lc) ? w.slot + w.li : 0u;
+    node = *(const uint4 *)((const char *)P.nodes + ((size_t)nidx << 4));
+    const float4 *tp = (const float4 *)((const char *)P.leaf_tris + (size_t)tslot * 48u);
+    T0 = tp[0]; T1 = tp[1]; T2 = tp[2];
+    asm volatile("" : "+v"(node.x), "+v"(node.y), "+v"(node.z), "+v"(node.w),
+                      "+v"(T0.x), "+v"(T0.y), "+v"(T0.z), "+v"(T0.w),
+                      "+v"(T1.x), "+v"(T1.y), "+v"(T1.z), "+v"(T1.w),
+                      "+v"(T2.x), "+v"(T2.y), "+v"(T2.z));
+}
+
+// One step of a walking lane; true when the walk has ended (w.t_hit etc. hold
+// the result, t_hit = +inf for a miss).
+template <int LDS_DEPTH>
+__device__ __forceinline__ bool walk_step(const TravScene &P, Walk &w, const uint4 &node, const float4 &T0,
+                                          const float4 &T1, const float4 &T2, uint2 *__restrict__ col,
+                                          uint2 *__restrict__ spill)
+{
+    bool finished = false;
+    if (!(w.ref & RT_REF_LEAF)) {
+        // descend, reference: src/kernels/kdtree.cl:229-260.  get_elem (:67-75)
+        // adds the masked-out zeros, which turns -0 into +0.
+        const uint32_t k = node.y;
+        const float b = __uint_as_float(node.x);
+        const float ok = ((k == 0) ? w.o.x : ((k == 1) ? w.o.y : w.o.z)) + 0.0f;
+        const float dk = ((k == 0) ? w.d.x : ((k == 1) ? w.d.y : w.d.z)) + 0.0f;
+        const float t_split = (b - ok) / dk;
+        const bool left_close = (ok < b) || (ok == b && dk <= 0);
+        const uint32_t first = left_close ? node.z : node.w;
+        const uint32_t second = left_close ? node.w : node.z;
+        const bool c1 = (t_split > w.t_max || t_split <= 0);
+        const bool c2 = (t_split < w.t_min);
+        if (!c1 && !c2) {
+            const uint2 e = make_uint2(second, __float_as_uint(t_split));
+            if (w.sp < (uint32_t)LDS_DEPTH) col[w.sp * 64] = e;
+            else if (w.sp < RT_MAX_STACK) spill[w.sp - LDS_DEPTH] = e;
+            w.sp++;
+            w.t_max = t_split;
+        }
+        walk_enter(w, (c1 || !c2) ? first : second);
+    } else {
+        // leaf, reference: src/kernels/kdtree.cl:263-302
+        if (w.li < w.lc) {
+            if (w.li == 0 && w.lc == 31u) w.lc = __float_as_uint(T1.w);
+            float t, u, v;
+            if (tri_hit_edges(xyz(T0), xyz(T1), xyz(T2), w.o, w.d, t, u, v)) {
+                if (!(t <= 0) && t < w.t_hit) {
+                    w.t_hit = t; w.hu = u; w.hv = v; w.tri_indx = __float_as_uint(T0.w);
+                    if (w.t_hit < w.t_max) finished = true;
+                }
+            }
+            w.li++;
+        }
+        if (!finished && w.li >= w.lc) {
+            // leaf used up: the reference's outer loop test, then restart or pop
+            if ((P.root_ref & RT_REF_LEAF) || !(w.t_max < w.scene_t_max)) finished = true;
+            else if (w.sp == 0) {
+                w.t_min = w.t_max; w.t_max = w.scene_t_max;
+                walk_enter(w, P.root_ref);
+            } else {
+                w.sp--;
+                const uint2 e = (w.sp < (uint32_t)LDS_DEPTH) ? col[w.sp * 64] : spill[w.sp - LDS_DEPTH];
+                w.t_min = __uint_as_float(e.y);
+                if (w.sp == 0) w.t_max = w.scene_t_max;
+                else {
+                    const uint2 below = (w.sp - 1 < (uint32_t)LDS_DEPTH) ? col[(w.sp - 1) * 64] : spill[w.sp - 1 - LDS_DEPTH];
+                    w.t_max = __uint_as_float(below.y);
+                }
+                walk_enter(w, e.x);
+            }
+        }
+    }
+    return finished;
+}
+
+__device__ __forceinline__ Hit walk_result(const Walk &w)
+{
+    Hit h;
+    if (!isinf(w.t_hit)) { h.tri = w.tri_indx; h.t = w.t_hit; h.u = w.hu; h.v = w.hv; }
+    else { h.tri = 0; h.t = 0.f; h.u = 0.f; h.v = 0.f; }
+    return h;
+}
+
+// Wave-uniform hand-out of consecutive work items: one atomicAdd claims CHUNK
+// items for the wave; `take` gives the calling lanes (those with want == true)
+// consecutive indices by prefix rank.  Returns the lane's index or ~0u.
+struct WorkQueue {
+    uint32_t next = 0, end = 0;
+    bool exhausted = false;
+};
+
+template <int CHUNK>
+__device__ __forceinline__ uint32_t queue_take(WorkQueue &q, bool want, uint32_t n, uint32_t *__restrict__ counter)
+{
+    const unsigned long long mask = __ballot(want);
+    const uint32_t nwant = (uint32_t)__popcll(mask);
+    if (q.exhausted || nwant == 0) return ~0u;
+    if (q.next >= q.end) {
+        uint32_t base = 0;
+        if (threadIdx.x == 0) base = atomicAdd(counter, (uint32_t)CHUNK);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if (base >= n) { q.exhausted = true; return ~0u; }
+        q.next = base;
+        q.end = (n - base < (uint32_t)CHUNK) ? n : base + (uint32_t)CHUNK;
+    }
+    const uint32_t avail = q.end - q.next;
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+    const uint32_t mine = (want && rank < avail) ? q.next + rank : ~0u;
+    q.next += (nwant < avail) ? nwant : avail;
+    return mine;
+}
+
+// kdtree_intersection: every ray of ray_o/ray_d[0..n) -> hits[0..n).
 template <int LDS_DEPTH, int REFILL_MIN, int CHUNK>
 __global__ __launch_bounds__(64) void k_kd_intersect(TravScene P, const float4 *__restrict__ ray_o,
                                                      const float4 *__restrict__ ray_d, Hit *__restrict__ hits,
@@ -169,155 +328,35 @@ __global__ __launch_bounds__(64) void k_kd_intersect(TravScene P, const float4 *
 {
     __shared__ uint2 stack[LDS_DEPTH * 64];
     uint2 spill[RT_MAX_STACK - LDS_DEPTH];
-    const uint32_t lane = threadIdx.x;
-    uint2 *const col = stack + lane;
+    uint2 *const col = stack + threadIdx.x;
 
-    // wave-uniform: the chunk of ray indices this wave is handing out
-    uint32_t chunk_next = 0, chunk_end = 0;
-    bool exhausted = false;
-
-    // per-lane ray state
-    bool active = false;
-    uint32_t ridx = 0, sp = 0, tri_indx = 0;
-    f3 o = mk3(0.f, 0.f, 0.f), d = mk3(0.f, 0.f, 0.f);
-    float t_min = 0.f, t_max = 0.f, scene_t_max = 0.f, t_hit = RT_INF, hu = 0.f, hv = 0.f;
-    uint32_t ref = 0;                       // where the lane stands: interior index or leaf descriptor
-    uint32_t li = 0, lc = 0, slot = 0;      // leaf progress: triangle li of lc, first slot
+    WorkQueue q;
+    Walk w = {};
+    bool walking = false;
+    uint32_t ridx = 0;
 
     for (;;) {
         // ---- hand new rays to idle lanes -----------------------------------
-        const unsigned long long idle = __ballot(!active);
-        const uint32_t nidle = (uint32_t)__popcll(idle);
-        if (!exhausted && nidle >= (uint32_t)REFILL_MIN) {
-            if (chunk_next >= chunk_end) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(counter, (uint32_t)CHUNK);
-                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                if (base >= n) exhausted = true;
-                else { chunk_next = base; chunk_end = (n - base < (uint32_t)CHUNK) ? n : base + (uint32_t)CHUNK; }
-            }
-            if (!exhausted) {
-                const uint32_t avail = chunk_end - chunk_next;
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32),
-                                                                __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
-                if (!active && rank < avail) {
-                    ridx = chunk_next + rank;
-                    o = xyz(ray_o[ridx]);
-                    d = xyz(ray_d[ridx]);
-                    // getTBoundingBox, reference: src/kernels/collision.cl:71-86
-                    float scene_t_min = 0.f;
-                    scene_t_max = RT_INF;
-                    f3 inv = mk3(1 / d.x, 1 / d.y, 1 / d.z);
-                    f3 t0 = (P.smin - o) * inv, t1 = (P.smax - o) * inv;
-                    f3 sm = mk3(cl_min(t0.x, t1.x), cl_min(t0.y, t1.y), cl_min(t0.z, t1.z));
-                    f3 bg = mk3(cl_max(t0.x, t1.x), cl_max(t0.y, t1.y), cl_max(t0.z, t1.z));
-                    scene_t_min = cl_max(scene_t_min, cl_max(sm.x, cl_max(sm.y, sm.z)));
-                    scene_t_max = cl_min(scene_t_max, cl_min(bg.x, cl_min(bg.y, bg.z)));
-                    if (!(scene_t_min < scene_t_max)) scene_t_max = -RT_INF;
-                    t_hit = RT_INF; hu = 0.f; hv = 0.f; tri_indx = 0; sp = 0;
-                    t_min = t_max = scene_t_min;
-                    if (t_max < scene_t_max) {          // first pass of the reference's outer loop: start at the root
-                        t_min = t_max; t_max = scene_t_max;
-                        ref = P.root_ref;
-                        lc = RT_REF_COUNT(ref); slot = ref & RT_REF_SLOT_MASK; li = 0;
-                        active = true;
-                    } else {
-                        Hit miss; miss.tri = 0; miss.t = 0.f; miss.u = 0.f; miss.v = 0.f;
-                        hits[ridx] = miss;
-                    }
-                }
-                chunk_next += (nidle < avail) ? nidle : avail;
+        const uint32_t nidle = (uint32_t)__popcll(__ballot(!walking));
+        if (!q.exhausted && nidle >= (uint32_t)REFILL_MIN) {
+            const uint32_t mine = queue_take<CHUNK>(q, !walking, n, counter);
+            if (mine != ~0u) {
+                ridx = mine;
+                w.o = xyz(ray_o[ridx]);
+                w.d = xyz(ray_d[ridx]);
+                walking = walk_begin(P, w);
+                if (!walking) hits[ridx] = walk_result(w);
             }
         }
-        if (!__any(active)) {
-            if (exhausted) break;
+        if (!__any(walking)) {
+            if (q.exhausted) break;
             continue;
         }
-
-        // ---- fetch what every lane stands on ----------------------------------
-        // Issued by all lanes outside any divergent branch (lanes with nothing to
-        // fetch read element 0, one shared cache line), so the wave pays a single
-        // memory round trip per trip of the loop.
-        const bool at_leaf = (ref & RT_REF_LEAF) != 0;
-        const uint32_t nidx = (active && !at_leaf) ? ref : 0u;
-        const uint32_t tslot = (active && at_leaf && li < lc) ? slot + li : 0u;
-        uint4 node = P.nodes[nidx];
-        const float4 *tp = P.leaf_tris + 3 * (size_t)tslot;
-        float4 T0 = tp[0], T1 = tp[1], T2 = tp[2];
-        // Pin the four loads here: left alone, the compiler sinks each one into
-        // the branch that uses it and the wave then waits for memory twice per trip.
-        asm volatile("" : "+v"(node.x), "+v"(node.y), "+v"(node.z), "+v"(node.w),
-                          "+v"(T0.x), "+v"(T0.y), "+v"(T0.z), "+v"(T0.w),
-                          "+v"(T1.x), "+v"(T1.y), "+v"(T1.z), "+v"(T1.w),
-                          "+v"(T2.x), "+v"(T2.y), "+v"(T2.z));
-
-        // ---- one step per lane ----------------------------------------------
-        if (active) {
-            bool finished = false, moved = false;
-            if (!at_leaf) {
-                // descend, reference: src/kernels/kdtree.cl:229-260.  get_elem (:67-75)
-                // adds the masked-out zeros, which turns -0 into +0.
-                const uint32_t k = node.y;
-                const float b = __uint_as_float(node.x);
-                const float ok = ((k == 0) ? o.x : ((k == 1) ? o.y : o.z)) + 0.0f;
-                const float dk = ((k == 0) ? d.x : ((k == 1) ? d.y : d.z)) + 0.0f;
-                const float t_split = (b - ok) / dk;
-                const bool left_close = (ok < b) || (ok == b && dk <= 0);
-                const uint32_t first = left_close ? node.z : node.w;
-                const uint32_t second = left_close ? node.w : node.z;
-                const bool c1 = (t_split > t_max || t_split <= 0);
-                const bool c2 = (t_split < t_min);
-                ref = (c1 || !c2) ? first : second;
-                if (!c1 && !c2) {
-                    const uint2 e = make_uint2(second, __float_as_uint(t_split));
-                    if (sp < (uint32_t)LDS_DEPTH) col[sp * 64] = e;
-                    else if (sp < RT_MAX_STACK) spill[sp - LDS_DEPTH] = e;
-                    sp++;
-                    t_max = t_split;
-                }
-                moved = true;
-            } else {
-                // leaf, reference: src/kernels/kdtree.cl:263-302
-                if (li < lc) {
-                    if (li == 0 && lc == 31u) lc = __float_as_uint(T1.w);
-                    float t, u, v;
-                    if (tri_hit_edges(xyz(T0), xyz(T1), xyz(T2), o, d, t, u, v)) {
-                        if (!(t <= 0) && t < t_hit) {
-                            t_hit = t; hu = u; hv = v; tri_indx = __float_as_uint(T0.w);
-                            if (t_hit < t_max) finished = true;
-                        }
-                    }
-                    li++;
-                }
-                if (!finished && li >= lc) {
-                    // leaf used up: the reference's outer loop test, then restart or pop
-                    if ((P.root_ref & RT_REF_LEAF) || !(t_max < scene_t_max)) finished = true;
-                    else if (sp == 0) {
-                        ref = P.root_ref; t_min = t_max; t_max = scene_t_max;
-                        moved = true;
-                    } else {
-                        sp--;
-                        const uint2 e = (sp < (uint32_t)LDS_DEPTH) ? col[sp * 64] : spill[sp - LDS_DEPTH];
-                        ref = e.x;
-                        t_min = __uint_as_float(e.y);
-                        if (sp == 0) t_max = scene_t_max;
-                        else {
-                            const uint2 below = (sp - 1 < (uint32_t)LDS_DEPTH) ? col[(sp - 1) * 64] : spill[sp - 1 - LDS_DEPTH];
-                            t_max = __uint_as_float(below.y);
-                        }
-                        moved = true;
-                    }
-                }
-            }
-            if (finished) {
-                Hit h;
-                if (!isinf(t_hit)) { h.tri = tri_indx; h.t = t_hit; h.u = hu; h.v = hv; }
-                else { h.tri = 0; h.t = 0.f; h.u = 0.f; h.v = 0.f; }
-                hits[ridx] = h;
-                active = false;
-            } else if (moved) {
-                lc = RT_REF_COUNT(ref); slot = ref & RT_REF_SLOT_MASK; li = 0;   // meaningful when ref is a leaf
-            }
+        uint4 node; float4 T0, T1, T2;
+        walk_fetch(P, w, walking, node, T0, T1, T2);
+        if (walking && walk_step<LDS_DEPTH>(P, w, node, T0, T1, T2, col, spill)) {
+            hits[ridx] = walk_result(w);
+            walking = false;
         }
     }
 }
@@ -486,6 +525,106 @@ __global__ void k_spath_trace(const float4 *__restrict__ tri_shade, float4 *__re
     ray_d[i] = mk4(nd, 0.f);
     prog_a[i] = pa;
     prog_b[i] = pb;
+}
+
+// ---------------------------------------------------------------------------
+// Several render iterations in one launch.
+//
+// With one launch per bounce the whole GPU waits, every iteration, for the
+// single longest ray of the frame (bounce rays: 24 steps on average, more than
+// a thousand for the worst), and each wave is busy for only about half of the
+// launch.  Pixels never interact, so here a lane keeps ONE pixel for `iters`
+// consecutive iterations -- walk its current ray, advance its RNG word, shade,
+// walk the new ray, ... exactly the per-pixel sequence of
+// xorshift_batch -> kdtree_intersection -> segmented_path_trace -- with the
+// path state in registers, and only then takes the next pixel from the work
+// queue.  A long ray now delays nothing but its own pixel.  rv[k] is the
+// random_value of the k-th iteration of the batch (the reference draws one per
+// launch, src/spath_raytracer.c:321).
+//
+// Shading is much heavier per call than a walk step, so lanes whose walk has
+// ended wait until SHADE_MIN of them can be served together (or nothing else is
+// left to do); the same service pass hands pixels to free lanes.
+// ---------------------------------------------------------------------------
+struct SpathDev {
+    const float4 *tri_shade;
+    float4 *out_tex, *ray_o, *ray_d;
+    const float4 *origin_o, *origin_d;
+    Hit *hits;
+    const Hit *source_hits;
+    float4 *prog_a, *prog_b;
+    uint32_t *random;
+};
+
+template <int LDS_DEPTH, int SHADE_MIN, int CHUNK>
+__global__ __launch_bounds__(64) void k_spath_run(TravScene P, SpathDev B, uint32_t n, uint32_t iters,
+                                                  const uint32_t *__restrict__ rv, uint32_t *__restrict__ counter)
+{
+    __shared__ uint2 stack[LDS_DEPTH * 64];
+    uint2 spill[RT_MAX_STACK - LDS_DEPTH];
+    uint2 *const col = stack + threadIdx.x;
+
+    enum { FREE = 0, WALK = 1, DONE = 2 };
+    WorkQueue q;
+    Walk w = {};
+    uint32_t mode = FREE, pix = 0, it = 0, rnd = 0;
+    float4 pa = make_float4(0, 0, 0, 0), pb = pa;
+
+    for (;;) {
+        const uint32_t ndone = (uint32_t)__popcll(__ballot(mode == DONE));
+        const uint32_t nfree = (uint32_t)__popcll(__ballot(mode == FREE));
+        const uint32_t nwalk = 64u - ndone - nfree;
+        const uint32_t waiting = ndone + (q.exhausted ? 0u : nfree);
+        if (waiting >= (uint32_t)SHADE_MIN || (nwalk == 0 && waiting > 0)) {
+            bool fresh = false;          // lane holds a new ray in w.o / w.d
+            // (a) finish the iteration of lanes whose walk has ended
+            if (mode == DONE) {
+                const Hit h = walk_result(w);
+                rnd = ((rnd << 1) | (rnd >> 31)) + 1;                 // xorshift_batch
+                if (__float_as_uint(pa.w) == 2048u) {                 // reference: path.cl:145-152
+                    w.o = mk3(0.f, 0.f, 0.f); w.d = mk3(0.f, 0.f, 0.f);
+                } else {
+                    f3 no, nd;
+                    spath_step(B.tri_shade, h, w.o, w.d, rnd, rv[it], pix, B.out_tex, B.origin_o, B.origin_d,
+                               B.source_hits, pa, pb, no, nd);
+                    w.o = no; w.d = nd;
+                }
+                it++;
+                if (it == iters) {       // leave the buffers as the last per-iteration launches would
+                    B.ray_o[pix] = mk4(w.o, 0.f);
+                    B.ray_d[pix] = mk4(w.d, 0.f);
+                    B.prog_a[pix] = pa;
+                    B.prog_b[pix] = pb;
+                    B.random[pix] = rnd;
+                    B.hits[pix] = h;
+                    mode = FREE;
+                } else {
+                    fresh = true;
+                }
+            }
+            // (b) free lanes take the next pixels
+            const uint32_t mine = queue_take<CHUNK>(q, mode == FREE, n, counter);
+            if (mine != ~0u) {
+                pix = mine;
+                w.o = xyz(B.ray_o[pix]);
+                w.d = xyz(B.ray_d[pix]);
+                pa = B.prog_a[pix];
+                pb = B.prog_b[pix];
+                rnd = B.random[pix];
+                it = 0;
+                fresh = true;
+            }
+            // (c) start the walk of every new ray
+            if (fresh) mode = walk_begin(P, w) ? WALK : DONE;
+        }
+        if (!__any(mode == WALK)) {
+            if (q.exhausted && !__any(mode == DONE)) break;
+            continue;
+        }
+        uint4 node; float4 T0, T1, T2;
+        walk_fetch(P, w, mode == WALK, node, T0, T1, T2);
+        if (mode == WALK && walk_step<LDS_DEPTH>(P, w, node, T0, T1, T2, col, spill)) mode = DONE;
+    }
 }
 
 // xorshift_batch, reference: src/kernels/path.cl:421-426
@@ -815,6 +954,44 @@ void launch_kd_intersect(rt_device *dev, const TravScene &P, const float4 *ro, c
     }
 }
 
+
+template <int LDS_DEPTH, int SHADE_MIN, int CHUNK>
+void launch_run_variant(rt_device *dev, const TravScene &P, const SpathDev &B, uint32_t n, uint32_t iters,
+                        const uint32_t *rv)
+{
+    auto kern = k_spath_run<LDS_DEPTH, SHADE_MIN, CHUNK>;
+    static int blocks_per_cu = 0;
+    if (!blocks_per_cu) {
+        RT_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kern, 64, 0));
+        if (blocks_per_cu < 1) blocks_per_cu = 1;
+    }
+    unsigned grid = (unsigned)blocks_per_cu * (unsigned)dev->props.multiProcessorCount;
+    const unsigned need = blocks_for(n, 64);
+    if (grid > need) grid = need;
+    uint32_t *counter = dev->counters + 16 * dev->current;
+    RT_HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(uint32_t), dev->stream));
+    rt_launch_timer tm(dev, RT_K_SPATH_RUN);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, dev->stream, P, B, n, iters, rv, counter);
+    RT_HIP_CHECK(hipGetLastError());
+}
+
+void launch_spath_run(rt_device *dev, const TravScene &P, const SpathDev &B, uint32_t n, uint32_t iters, const uint32_t *rv)
+{
+    static int variant = -1;
+    if (variant < 0) {
+        const char *e = getenv("RT_RUN_VARIANT");
+        variant = e ? atoi(e) : 0;
+    }
+    switch (variant) {
+    case 1: launch_run_variant<12, 16, 256>(dev, P, B, n, iters, rv); break;
+    case 2: launch_run_variant<12, 32, 256>(dev, P, B, n, iters, rv); break;
+    case 3: launch_run_variant<16, 24, 256>(dev, P, B, n, iters, rv); break;
+    case 4: launch_run_variant<12, 8, 256>(dev, P, B, n, iters, rv); break;
+    case 5: launch_run_variant<8, 24, 256>(dev, P, B, n, iters, rv); break;
+    default: launch_run_variant<12, 24, 256>(dev, P, B, n, iters, rv); break;
+    }
+}
+
 }  // namespace
 
 #define RT_AFTER_LAUNCH() RT_HIP_CHECK(hipGetLastError())
@@ -879,6 +1056,26 @@ void rt_k_xorshift(rt_device *dev, rt_mem random, uint32_t n)
     rt_launch_timer tm(dev, RT_K_XORSHIFT);
     hipLaunchKernelGGL(k_xorshift, dim3(blocks_for(n, 256)), dim3(256), 0, dev->stream, (uint32_t *)random, n);
     RT_AFTER_LAUNCH();
+}
+
+void rt_k_spath_run(rt_device *dev, const rt_kd_view *kd, const rt_spath_buffers *b, uint32_t n, uint32_t iters,
+                    rt_mem random_values)
+{
+    if (!n || !iters) return;
+    check_kd(kd, "rt_k_spath_run");
+    TravScene P;
+    P.nodes = (const uint4 *)kd->nodes;
+    P.leaf_tris = (const float4 *)kd->leaf_tris;
+    P.smin = host3(kd->scene_min);
+    P.smax = host3(kd->scene_max);
+    P.root_ref = kd->root_ref;
+    SpathDev B;
+    B.tri_shade = (const float4 *)kd->tri_shade;
+    B.out_tex = (float4 *)b->out_tex; B.ray_o = (float4 *)b->ray_o; B.ray_d = (float4 *)b->ray_d;
+    B.origin_o = (const float4 *)b->origin_o; B.origin_d = (const float4 *)b->origin_d;
+    B.hits = (Hit *)b->hits; B.source_hits = (const Hit *)b->source_hits;
+    B.prog_a = (float4 *)b->prog_a; B.prog_b = (float4 *)b->prog_b; B.random = (uint32_t *)b->random;
+    launch_spath_run(dev, P, B, n, iters, (const uint32_t *)random_values);
 }
 
 void rt_k_resolve_avg(rt_device *dev, rt_mem out_u32, rt_mem out_tex, uint32_t n)
