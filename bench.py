@@ -188,7 +188,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    kname = "kd_intersect"
+    # dominant kernel: the multi-iteration launch (traversal + shading of a batch of
+    # iterations), or the traversal launch when iterations are launched one by one
+    kname = "kd_intersect" if args.separate_kernels else "spath_run"
     launches, kms = r.timing_get(kname)
     _, shade_ms = r.timing_get("spath_trace")
     r.timing(False)
@@ -200,7 +202,9 @@ def main():
         per_ray, b_gather = gather_stats(rt, sc, r, threads)
         b_ray = B_STREAM + b_gather
         avg_ms = kms / max(launches, 1)
-        achieved = (b_ray * n_local) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        iters_per_launch = args.steps / max(launches, 1)      # 1 with --separate-kernels
+        rays_per_launch = n_local * iters_per_launch
+        achieved = (b_ray * rays_per_launch) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
@@ -219,7 +223,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": kname, "avg_launch_ms": round(avg_ms, 4), "launches": launches,
-                         "bytes_per_ray": round(b_ray, 1), "rays_per_launch": n_local,
+                         "bytes_per_ray": round(b_ray, 1), "rays_per_launch": int(rays_per_launch),
+                         "iterations_per_launch": round(iters_per_launch, 2),
                          "shade_avg_launch_ms": round(shade_ms / max(launches, 1), 4),
                          "per_ray": {k: round(v, 3) for k, v in per_ray.items()}},
         }

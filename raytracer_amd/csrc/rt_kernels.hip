@@ -162,6 +162,17 @@ struct TravScene {
     uint32_t root_ref;
 };
 
+// Component k (0..2) of v.  Written on copies pinned in registers: a plain
+// "k==0 ? v.x : ..." chain on members of a struct held by reference is turned by
+// the compiler into a dynamically indexed load, which drags the whole struct
+// into scratch memory.
+__device__ __forceinline__ float pick_axis(f3 v, uint32_t k)
+{
+    float x = v.x, y = v.y, z = v.z;
+    asm volatile("" : "+v"(x), "+v"(y), "+v"(z));
+    return (k == 0) ? x : ((k == 1) ? y : z);
+}
+
 // Registers of one lane's walk.
 struct Walk {
     f3 o, d;
@@ -232,8 +243,8 @@ __device__ __forceinline__ bool walk_step(const TravScene &P, Walk &w, const uin
         // adds the masked-out zeros, which turns -0 into +0.
         const uint32_t k = node.y;
         const float b = __uint_as_float(node.x);
-        const float ok = ((k == 0) ? w.o.x : ((k == 1) ? w.o.y : w.o.z)) + 0.0f;
-        const float dk = ((k == 0) ? w.d.x : ((k == 1) ? w.d.y : w.d.z)) + 0.0f;
+        const float ok = pick_axis(w.o, k) + 0.0f;
+        const float dk = pick_axis(w.d, k) + 0.0f;
         const float t_split = (b - ok) / dk;
         const bool left_close = (ok < b) || (ok == b && dk <= 0);
         const uint32_t first = left_close ? node.z : node.w;
@@ -546,6 +557,13 @@ __global__ void k_spath_trace(const float4 *__restrict__ tri_shade, float4 *__re
 // ended wait until SHADE_MIN of them can be served together (or nothing else is
 // left to do); the same service pass hands pixels to free lanes.
 // ---------------------------------------------------------------------------
+// The kernel is VALU-issue bound, not latency bound: registers are worth more
+// than a sixth wave per SIMD (capping the allocation at 80 spills path state
+// into scratch inside the loop).
+#ifndef RT_RUN_WAVES_PER_EU
+#define RT_RUN_WAVES_PER_EU 5
+#endif
+
 struct SpathDev {
     const float4 *tri_shade;
     float4 *out_tex, *ray_o, *ray_d;
@@ -557,7 +575,7 @@ struct SpathDev {
 };
 
 template <int LDS_DEPTH, int SHADE_MIN, int CHUNK>
-__global__ __launch_bounds__(64) void k_spath_run(TravScene P, SpathDev B, uint32_t n, uint32_t iters,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, RT_RUN_WAVES_PER_EU))) void k_spath_run(TravScene P, SpathDev B, uint32_t n, uint32_t iters,
                                                   const uint32_t *__restrict__ rv, uint32_t *__restrict__ counter)
 {
     __shared__ uint2 stack[LDS_DEPTH * 64];
