@@ -115,6 +115,7 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("RT_BENCH_WORKLOAD", "c3"), choices=sorted(WORKLOADS))
     ap.add_argument("--separate-kernels", action="store_true", help="three launches per iteration, as the reference")
     ap.add_argument("--max-batch", type=int, default=None, help="most iterations folded into one launch")
+    ap.add_argument("--no-reorder", action="store_true", help="serve pixels in index order in every batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
@@ -149,7 +150,7 @@ def main():
     r.build()
     t_build = time.perf_counter() - t0
     r.init_spath(seed=1, separate_kernels=args.separate_kernels, resolve_interval=50, quiet=True,
-                 max_batch=args.max_batch)
+                 max_batch=args.max_batch, reorder=not args.no_reorder)
     r.spath_prepass(num_iterations=1 << 30)
     if rank == 0:
         log(f"[bench] {desc}: {sc.num_tris} triangles, scene {t_scene:.1f}s, build {t_build:.1f}s, "

@@ -63,7 +63,7 @@ void   rt_mem_copy(rt_device *dev, rt_mem dst, rt_mem src, size_t bytes);       
 /* ---- timing with HIP events on the device's stream ---------------------- */
 enum {
     RT_K_GENERATE_RAYS = 0, RT_K_KD_INTERSECT, RT_K_SPATH_INIT, RT_K_SPATH_TRACE, RT_K_XORSHIFT,
-    RT_K_RESOLVE_AVG, RT_K_CAST_RAYS, RT_K_PATH_TRACE, RT_K_F_AVERAGE, RT_K_F_TO_BYTE, RT_K_SPATH_RUN, RT_K_COUNT
+    RT_K_RESOLVE_AVG, RT_K_CAST_RAYS, RT_K_PATH_TRACE, RT_K_F_AVERAGE, RT_K_F_TO_BYTE, RT_K_SPATH_RUN, RT_K_PIXEL_ORDER, RT_K_COUNT
 };
 /* When enabled, every launch below is bracketed by two events; the totals are
    read back (after a sync) with rt_timing_get and cleared with rt_timing_reset. */
@@ -158,9 +158,17 @@ void rt_k_xorshift(rt_device *dev, rt_mem random, uint32_t n);
    segmented_path_trace for every pixel, iters times -- in ONE launch
    (the loop body of src/spath_raytracer.c:364-385 repeated).  random_values is a
    device array of iters words: the random_value of each iteration, in order.
-   Buffers end up exactly as iters rounds of the three separate launches leave them. */
+   Buffers end up exactly as iters rounds of the three separate launches leave them.
+   cost (n words, required) receives the number of walk steps each pixel took;
+   order (n words, or NULL for 0,1,2,...) is the sequence in which pixels are
+   handed to lanes -- scheduling only, results do not depend on it. */
 void rt_k_spath_run(rt_device *dev, const rt_kd_view *kd, const rt_spath_buffers *b, uint32_t n, uint32_t iters,
-                    rt_mem random_values);
+                    rt_mem random_values, rt_mem cost, rt_mem order);
+
+/* Pixel indices sorted by decreasing cost >> shift (counting sort, 256 buckets)
+   into order[0..n); hist256 is 256 words of scratch.  No counterpart in the
+   reference: it only feeds the scheduling of the next rt_k_spath_run. */
+void rt_k_pixel_order(rt_device *dev, rt_mem cost, rt_mem order, rt_mem hist256, uint32_t n, uint32_t shift);
 
 /* f_buffer_to_byte_buffer_avg (src/kernels/path.cl:428-444; host src/spath_raytracer.c:252-277). */
 void rt_k_resolve_avg(rt_device *dev, rt_mem out_u32, rt_mem out_tex, uint32_t n);

@@ -52,6 +52,11 @@ typedef struct spath_raytracer_context {
     unsigned int pending;             /* iterations accepted by spath_raytracer_render but not launched yet */
     unsigned int *pending_values;     /* their random values */
     rt_mem       cl_random_value_buffer;
+    rt_mem       cl_pixel_cost_buffer;   /* walk steps per pixel in the last batch */
+    rt_mem       cl_pixel_order_buffer;  /* pixels by decreasing cost: service order of the next batch */
+    rt_mem       cl_cost_hist_buffer;
+    bool         order_valid;
+    int          no_reorder;             /* 1: always serve pixels in index order */
 } spath_raytracer_context;
 
 spath_raytracer_context *init_spath_raytracer_context(struct _rt_ctx *rctx);   /* src/spath_raytracer.c:39-116 */

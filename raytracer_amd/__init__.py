@@ -27,7 +27,7 @@ RT_RNG_LIBC, RT_RNG_SPLITMIX = 0, 1
 
 KERNEL_IDS = {"generate_rays": 0, "kd_intersect": 1, "spath_init": 2, "spath_trace": 3, "xorshift": 4,
               "resolve_avg": 5, "cast_rays": 6, "path_trace": 7, "f_buffer_average": 8, "f_to_byte": 9,
-              "spath_run": 10}
+              "spath_run": 10, "pixel_order": 11}
 
 HIT_DT = np.dtype([("tri", "<u4"), ("t", "<f4"), ("u", "<f4"), ("v", "<f4")])
 
@@ -129,7 +129,9 @@ class spath_raytracer_context(C.Structure):
                 ("cl_spath_progress_b_buffer", C.c_void_p), ("rng_mode", C.c_int), ("rng_seed", C.c_uint),
                 ("rng_launch", C.c_uint), ("resolve_interval", C.c_uint), ("separate_kernels", C.c_int),
                 ("quiet", C.c_bool), ("max_batch", C.c_uint), ("pending", C.c_uint),
-                ("pending_values", C.POINTER(C.c_uint)), ("cl_random_value_buffer", C.c_void_p)]
+                ("pending_values", C.POINTER(C.c_uint)), ("cl_random_value_buffer", C.c_void_p),
+                ("cl_pixel_cost_buffer", C.c_void_p), ("cl_pixel_order_buffer", C.c_void_p),
+                ("cl_cost_hist_buffer", C.c_void_p), ("order_valid", C.c_bool), ("no_reorder", C.c_int)]
 
 
 class rt_device_props(C.Structure):
@@ -150,7 +152,7 @@ _ABI_OFFSETS = [("raytracer_context", "stat_scene"), ("raytracer_context", "rcl"
                 ("kd_tree", "bounds"), ("kd_tree", "buffer"), ("kd_tree", "flat"), ("kd_tree", "view"),
                 ("kd_tree", "build_threads"), ("spath_raytracer_context", "cl_random_buffer"),
                 ("spath_raytracer_context", "rng_mode"), ("spath_raytracer_context", "quiet"), ("spath_raytracer_context", "max_batch"),
-                ("spath_raytracer_context", "cl_random_value_buffer"),
+                ("spath_raytracer_context", "cl_random_value_buffer"), ("spath_raytracer_context", "no_reorder"),
                 ("path_raytracer_context", "cl_path_output_buffer")]
 
 # every symbol the headers under include/ declare
@@ -160,7 +162,7 @@ EXPORTED_SYMBOLS = [
     "rt_device_stream", "rt_device_ordinal", "rt_device_select_stream", "rt_mem_alloc", "rt_mem_free", "rt_mem_upload", "rt_mem_download",
     "rt_mem_zero", "rt_mem_copy", "rt_timing_enable", "rt_timing_reset", "rt_timing_get", "rt_kernel_name",
     "rt_k_generate_rays", "rt_k_kd_intersect", "rt_k_spath_init", "rt_k_spath_trace", "rt_k_xorshift",
-    "rt_k_spath_run", "rt_k_resolve_avg", "rt_k_cast_rays", "rt_k_path_trace", "rt_k_f_buffer_average",
+    "rt_k_spath_run", "rt_k_pixel_order", "rt_k_resolve_avg", "rt_k_cast_rays", "rt_k_path_trace", "rt_k_f_buffer_average",
     "rt_k_f_to_byte",
     # parallel.h
     "cl_info", "create_context", "load_program_raw", "load_program_url", "gen_rgb_image", "gen_grayscale_buffer",
@@ -243,7 +245,8 @@ def lib():
     L.rt_k_spath_init.argtypes = [vp, C.POINTER(rt_kd_view), C.POINTER(rt_spath_buffers), u32, u32, u32, u32]
     L.rt_k_spath_trace.argtypes = [vp, C.POINTER(rt_kd_view), C.POINTER(rt_spath_buffers), u32, u32, C.c_int]
     L.rt_k_xorshift.argtypes = [vp, vp, u32]
-    L.rt_k_spath_run.argtypes = [vp, C.POINTER(rt_kd_view), C.POINTER(rt_spath_buffers), u32, u32, vp]
+    L.rt_k_spath_run.argtypes = [vp, C.POINTER(rt_kd_view), C.POINTER(rt_spath_buffers), u32, u32, vp, vp, vp]
+    L.rt_k_pixel_order.argtypes = [vp, vp, vp, vp, u32, u32]
     L.rt_k_resolve_avg.argtypes = [vp, vp, vp, u32]
     L.rt_k_f_buffer_average.argtypes = [vp, vp, vp, u32, u32]
     L.rt_k_f_to_byte.argtypes = [vp, vp, vp, u32]
@@ -371,7 +374,7 @@ class Renderer:
         return self.scene.contents.kdt.contents
 
     def init_spath(self, seed: int = 1, separate_kernels: bool = False, resolve_interval: int = 50, quiet: bool = True,
-                   max_batch: int | None = None):
+                   max_batch: int | None = None, reorder: bool = True):
         if not self.built:
             self.build()
         self.spath = self.L.init_spath_raytracer_context(self.rctx)
@@ -383,6 +386,7 @@ class Renderer:
         c.quiet = quiet
         if max_batch is not None:
             c.max_batch = max_batch
+        c.no_reorder = 0 if reorder else 1
         return self.spath
 
     def spath_prepass(self, num_iterations: int | None = None):

@@ -31,7 +31,7 @@ size_t rt_abi_query(const char *name)
     OFFSET_OF(kd_tree, build_threads);
     OFFSET_OF(spath_raytracer_context, cl_random_buffer); OFFSET_OF(spath_raytracer_context, rng_mode);
     OFFSET_OF(spath_raytracer_context, quiet); OFFSET_OF(spath_raytracer_context, max_batch);
-    OFFSET_OF(spath_raytracer_context, cl_random_value_buffer);
+    OFFSET_OF(spath_raytracer_context, cl_random_value_buffer); OFFSET_OF(spath_raytracer_context, no_reorder);
     OFFSET_OF(path_raytracer_context, cl_path_output_buffer);
     OFFSET_OF(mesh, material_index); OFFSET_OF(material, reflectivity);
     OFFSET_OF(sphere, material_index); OFFSET_OF(plane, material_index);

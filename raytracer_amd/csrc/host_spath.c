@@ -77,6 +77,11 @@ spath_raytracer_context *init_spath_raytracer_context(struct _rt_ctx *rctx)
     c->pending = 0;
     c->pending_values = (unsigned int *)malloc(sizeof(unsigned int) * 1024);
     c->cl_random_value_buffer = rt_mem_alloc(dev, sizeof(unsigned int) * 1024);
+    c->cl_pixel_cost_buffer = rt_mem_alloc(dev, n * sizeof(unsigned int));
+    c->cl_pixel_order_buffer = rt_mem_alloc(dev, n * sizeof(unsigned int));
+    c->cl_cost_hist_buffer = rt_mem_alloc(dev, 256 * sizeof(unsigned int));
+    c->order_valid = false;
+    c->no_reorder = 0;
     return c;
 }
 
@@ -107,7 +112,16 @@ void spath_raytracer_flush(spath_raytracer_context *c)
     /* blocking upload: also orders this batch behind the previous one, so the
        table is not overwritten while a launch still reads it */
     rt_mem_upload(dev, c->cl_random_value_buffer, c->pending_values, sizeof(unsigned int) * c->pending);
-    rt_k_spath_run(dev, &rctx->stat_scene->kdt->view, &b, n, c->pending, c->cl_random_value_buffer);
+    rt_k_spath_run(dev, &rctx->stat_scene->kdt->view, &b, n, c->pending, c->cl_random_value_buffer,
+                   c->cl_pixel_cost_buffer, (c->order_valid && !c->no_reorder) ? c->cl_pixel_order_buffer : NULL);
+    if (!c->no_reorder && n >= 65536) {
+        /* the next batch serves the pixels that were heaviest in this one first;
+           bucket width ~ 1/64 of a typical pixel's cost (about 32 steps per iteration) */
+        unsigned int shift = 0;
+        while ((32u * c->pending) >> shift > 64u) shift++;
+        rt_k_pixel_order(dev, c->cl_pixel_cost_buffer, c->cl_pixel_order_buffer, c->cl_cost_hist_buffer, n, shift);
+        c->order_valid = true;
+    }
     c->pending = 0;
 }
 
@@ -132,6 +146,7 @@ void spath_raytracer_prepass(spath_raytracer_context *c)
     c->num_iterations = 2048 * 4;
     c->rng_launch = 0;
     c->pending = 0;
+    c->order_valid = false;
     if (c->rng_mode == RT_RNG_LIBC) srand((unsigned int)rt_time_ms());
     c->start_time = rt_time_ms();
 
@@ -218,6 +233,9 @@ void spath_raytracer_destroy(spath_raytracer_context *c)
     rt_mem_free(dev, c->cl_spath_progress_buffer);
     rt_mem_free(dev, c->cl_spath_progress_b_buffer);
     rt_mem_free(dev, c->cl_random_value_buffer);
+    rt_mem_free(dev, c->cl_pixel_cost_buffer);
+    rt_mem_free(dev, c->cl_pixel_order_buffer);
+    rt_mem_free(dev, c->cl_cost_hist_buffer);
     free(c->pending_values);
     free(c->random_buffer);
     free(c);

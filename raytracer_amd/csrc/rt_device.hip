@@ -5,7 +5,7 @@
 
 static const char *k_kernel_names[RT_K_COUNT] = {
     "generate_rays", "kd_intersect", "spath_init", "spath_trace", "xorshift",
-    "resolve_avg", "cast_rays", "path_trace", "f_buffer_average", "f_to_byte", "spath_run"};
+    "resolve_avg", "cast_rays", "path_trace", "f_buffer_average", "f_to_byte", "spath_run", "pixel_order"};
 
 extern "C" {
 

@@ -572,6 +572,8 @@ struct SpathDev {
     const Hit *source_hits;
     float4 *prog_a, *prog_b;
     uint32_t *random;
+    uint32_t *cost;             // out: walk steps each pixel took in this launch
+    const uint32_t *order;      // in: pixel to serve as j-th work item (nullptr = j)
 };
 
 template <int LDS_DEPTH, int SHADE_MIN, int CHUNK>
@@ -585,7 +587,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, RT_RUN_WA
     enum { FREE = 0, WALK = 1, DONE = 2 };
     WorkQueue q;
     Walk w = {};
-    uint32_t mode = FREE, pix = 0, it = 0, rnd = 0;
+    uint32_t mode = FREE, pix = 0, it = 0, rnd = 0, steps = 0;
     float4 pa = make_float4(0, 0, 0, 0), pb = pa;
 
     for (;;) {
@@ -615,6 +617,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, RT_RUN_WA
                     B.prog_b[pix] = pb;
                     B.random[pix] = rnd;
                     B.hits[pix] = h;
+                    B.cost[pix] = steps;
                     mode = FREE;
                 } else {
                     fresh = true;
@@ -623,7 +626,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, RT_RUN_WA
             // (b) free lanes take the next pixels
             const uint32_t mine = queue_take<CHUNK>(q, mode == FREE, n, counter);
             if (mine != ~0u) {
-                pix = mine;
+                pix = B.order ? B.order[mine] : mine;
+                steps = 0;
                 w.o = xyz(B.ray_o[pix]);
                 w.d = xyz(B.ray_d[pix]);
                 pa = B.prog_a[pix];
@@ -641,7 +645,75 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, RT_RUN_WA
         }
         uint4 node; float4 T0, T1, T2;
         walk_fetch(P, w, mode == WALK, node, T0, T1, T2);
-        if (mode == WALK && walk_step<LDS_DEPTH>(P, w, node, T0, T1, T2, col, spill)) mode = DONE;
+        if (mode == WALK) {
+            steps++;
+            if (walk_step<LDS_DEPTH>(P, w, node, T0, T1, T2, col, spill)) mode = DONE;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Heaviest pixels first.  A pixel's walk cost is stable from batch to batch
+// (its paths all start at the same primary hit), and a batch ends when the
+// last lane has finished its last pixel, so the next batch serves pixels in
+// order of decreasing cost of the previous one: 256-bucket counting sort,
+// buckets by cost >> shift, in three small launches (histogram, scan of the
+// buckets from heaviest to lightest, scatter).  Contention on the global
+// bucket counters is kept low by counting inside each workgroup in LDS first.
+// ---------------------------------------------------------------------------
+#define RT_COST_BUCKETS 256
+
+__device__ __forceinline__ uint32_t cost_bucket(uint32_t c, uint32_t shift)
+{
+    const uint32_t b = c >> shift;
+    return (RT_COST_BUCKETS - 1) - (b < RT_COST_BUCKETS - 1 ? b : RT_COST_BUCKETS - 1);   // heaviest -> bucket 0
+}
+
+__global__ __launch_bounds__(256) void k_cost_hist(const uint32_t *__restrict__ cost, uint32_t n, uint32_t shift,
+                                                    uint32_t *__restrict__ hist)
+{
+    __shared__ uint32_t local[RT_COST_BUCKETS];
+    local[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t i = blockIdx.x * 1024u + threadIdx.x, e = min(n, (blockIdx.x + 1u) * 1024u); i < e; i += 256u)
+        atomicAdd(&local[cost_bucket(cost[i], shift)], 1u);
+    __syncthreads();
+    if (local[threadIdx.x]) atomicAdd(&hist[threadIdx.x], local[threadIdx.x]);
+}
+
+// hist[b] -> first output position of bucket b (exclusive prefix sum); one workgroup.
+__global__ __launch_bounds__(256) void k_cost_scan(uint32_t *__restrict__ hist)
+{
+    __shared__ uint32_t v[RT_COST_BUCKETS];
+    v[threadIdx.x] = hist[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t sum = 0;
+        for (int b = 0; b < RT_COST_BUCKETS; b++) { const uint32_t c = v[b]; v[b] = sum; sum += c; }
+    }
+    __syncthreads();
+    hist[threadIdx.x] = v[threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void k_cost_scatter(const uint32_t *__restrict__ cost, uint32_t n, uint32_t shift,
+                                                       uint32_t *__restrict__ next, uint32_t *__restrict__ order)
+{
+    __shared__ uint32_t local[RT_COST_BUCKETS], base[RT_COST_BUCKETS];
+    local[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t rank[4], bucket[4];
+    const uint32_t first = blockIdx.x * 1024u + threadIdx.x;
+    for (int k = 0; k < 4; k++) {
+        const uint32_t i = first + 256u * k;
+        bucket[k] = (i < n) ? cost_bucket(cost[i], shift) : 0u;
+        rank[k] = (i < n) ? atomicAdd(&local[bucket[k]], 1u) : 0u;
+    }
+    __syncthreads();
+    base[threadIdx.x] = local[threadIdx.x] ? atomicAdd(&next[threadIdx.x], local[threadIdx.x]) : 0u;
+    __syncthreads();
+    for (int k = 0; k < 4; k++) {
+        const uint32_t i = first + 256u * k;
+        if (i < n) order[base[bucket[k]] + rank[k]] = i;
     }
 }
 
@@ -1076,8 +1148,21 @@ void rt_k_xorshift(rt_device *dev, rt_mem random, uint32_t n)
     RT_AFTER_LAUNCH();
 }
 
+void rt_k_pixel_order(rt_device *dev, rt_mem cost, rt_mem order, rt_mem hist256, uint32_t n, uint32_t shift)
+{
+    if (!n) return;
+    rt_launch_timer tm(dev, RT_K_PIXEL_ORDER);
+    RT_HIP_CHECK(hipMemsetAsync(hist256, 0, RT_COST_BUCKETS * sizeof(uint32_t), dev->stream));
+    hipLaunchKernelGGL(k_cost_hist, dim3(blocks_for(n, 1024)), dim3(256), 0, dev->stream, (const uint32_t *)cost, n,
+                       shift, (uint32_t *)hist256);
+    hipLaunchKernelGGL(k_cost_scan, dim3(1), dim3(256), 0, dev->stream, (uint32_t *)hist256);
+    hipLaunchKernelGGL(k_cost_scatter, dim3(blocks_for(n, 1024)), dim3(256), 0, dev->stream, (const uint32_t *)cost, n,
+                       shift, (uint32_t *)hist256, (uint32_t *)order);
+    RT_AFTER_LAUNCH();
+}
+
 void rt_k_spath_run(rt_device *dev, const rt_kd_view *kd, const rt_spath_buffers *b, uint32_t n, uint32_t iters,
-                    rt_mem random_values)
+                    rt_mem random_values, rt_mem cost, rt_mem order)
 {
     if (!n || !iters) return;
     check_kd(kd, "rt_k_spath_run");
@@ -1093,6 +1178,9 @@ void rt_k_spath_run(rt_device *dev, const rt_kd_view *kd, const rt_spath_buffers
     B.origin_o = (const float4 *)b->origin_o; B.origin_d = (const float4 *)b->origin_d;
     B.hits = (Hit *)b->hits; B.source_hits = (const Hit *)b->source_hits;
     B.prog_a = (float4 *)b->prog_a; B.prog_b = (float4 *)b->prog_b; B.random = (uint32_t *)b->random;
+    B.cost = (uint32_t *)cost;
+    B.order = (const uint32_t *)order;
+    if (!cost) { fprintf(stderr, "ERROR: rt_k_spath_run needs a per-pixel cost buffer\n"); exit(1); }
     launch_spath_run(dev, P, B, n, iters, (const uint32_t *)random_values);
 }
 

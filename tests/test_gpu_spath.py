@@ -105,3 +105,48 @@ def test_tile_equals_full_frame(rt, orc, small):
     assert_bits_equal(got, ref[y0:y0 + th], "strip vs full frame")
     st = oracle_spath_run(orc, sc, tree, w, th, seed, iters, y0=y0, full_h=h)
     assert_bits_equal(got.reshape(-1, 4), st.out_tex, "strip vs oracle strip")
+
+
+def test_batches_and_heaviest_first_order_do_not_change_results(rt, orc, small):
+    """A frame large enough for the cost-ordered scheduling (>= 65,536 pixels),
+    rendered in three batches (2 + 2 + 1 iterations; the 2nd and 3rd are served
+    heaviest pixel first), equals the oracle's iteration-by-iteration result."""
+    sc, tree = small
+    w, h, iters, seed = 256, 256, 5, 13
+    r = rt.Renderer(sc, w, h).build()
+    r.init_spath(seed=seed, resolve_interval=0, max_batch=2)
+    r.spath_prepass(num_iterations=iters)
+    r.spath_render(iters)
+    g = r.spath_state()
+    order = r.download(r.spath.contents.cl_pixel_order_buffer, np.uint32, w * h)
+    cost = r.download(r.spath.contents.cl_pixel_cost_buffer, np.uint32, w * h)
+    r.close()
+    st = oracle_spath_run(orc, sc, tree, w, h, seed, iters)
+    assert_bits_equal(g["out_tex"], st.out_tex, "out_tex")
+    assert_bits_equal(g["rays"], st.rays, "rays")
+    assert_bits_equal(g["progress"], st.progress, "progress")
+    assert_bits_equal(g["random"], st.random, "random")
+    hits_equal(g["results"], st.results, "hits")
+    # the order buffer is a permutation, heaviest bucket first
+    assert np.array_equal(np.sort(order), np.arange(w * h, dtype=np.uint32))
+    assert cost.max() > 0
+
+
+def test_deep_stack_scene_bit_exact(rt, orc):
+    """Rays through an 82k-triangle mesh need more stack levels than the LDS part
+    holds (the reference's own limit is 16): the spill path must agree too."""
+    sc = rt.scenes.icosphere_scene(6)
+    tree = orc.KdTree(sc.verts4, sc.idx4)
+    w, h, iters, seed = 128, 96, 4, 21
+    r = rt.Renderer(sc, w, h).build()
+    r.init_spath(seed=seed, resolve_interval=0)
+    r.spath_prepass(num_iterations=iters)
+    r.spath_render(iters)
+    g = r.spath_state()
+    r.close()
+    st = oracle_spath_run(orc, sc, tree, w, h, seed, iters)
+    _, stats = tree.intersect(st.rays, stats=True)
+    hits_equal(g["source_results"], st.source_results, "primary hits")
+    assert_bits_equal(g["out_tex"], st.out_tex, "out_tex")
+    assert_bits_equal(g["rays"], st.rays, "rays")
+    assert stats["max_stack"] > 12, stats
