@@ -485,7 +485,8 @@ void kd_tree_flatten(kd_tree *tree)
     free(f->nodes); free(f->leaf_tris);
     memset(f, 0, sizeof *f);
     if (!tree->root) return;
-    if (tree->num_traversal_nodes >= REF_LEAF || tree->num_indices_total >= (1u << REF_SLOT_BITS)) {
+    /* also keeps both device arrays below 4 GiB: the kernels use 32-bit byte offsets */
+    if (tree->num_traversal_nodes >= (1u << 28) || tree->num_indices_total >= (1u << REF_SLOT_BITS)) {
         fprintf(stderr, "ERROR: kd-tree too large for the flattened layout (%u interior nodes, %u leaf slots)\n",
                 tree->num_traversal_nodes, tree->num_indices_total);
         exit(1);

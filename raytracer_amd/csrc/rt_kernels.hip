@@ -162,20 +162,10 @@ struct TravScene {
     uint32_t root_ref;
 };
 
-// Component k (0..2) of v.  Written on copies pinned in registers: a plain
-// "k==0 ? v.x : ..." chain on members of a struct held by reference is turned by
-// the compiler into a dynamically indexed load, which drags the whole struct
-// into scratch memory.
-__device__ __forceinline__ float pick_axis(f3 v, uint32_t k)
-{
-    float x = v.x, y = v.y, z = v.z;
-    asm volatile("" : "+v"(x), "+v"(y), "+v"(z));
-    return (k == 0) ? x : ((k == 1) ? y : z);
-}
-
-// Registers of one lane's walk.
+// Registers of one lane's walk (the ray itself, o and d, stays in plain locals
+// of the kernel: selecting a component of a struct member by axis makes the
+// compiler index the struct in memory, which drags all of it into scratch).
 struct Walk {
-    f3 o, d;
     float t_min, t_max, scene_t_max, t_hit, hu, hv;
     uint32_t tri_indx, sp;
     uint32_t ref;            // where the lane stands: interior index or leaf descriptor
@@ -188,16 +178,16 @@ __device__ __forceinline__ void walk_enter(Walk &w, uint32_t ref)
     w.lc = RT_REF_COUNT(ref); w.slot = ref & RT_REF_SLOT_MASK; w.li = 0;   // meaningful when ref is a leaf
 }
 
-// Start a ray (w.o, w.d set by the caller): slab clip against the scene box
+// Start the walk of ray (o, d): slab clip against the scene box
 // (getTBoundingBox, reference: src/kernels/collision.cl:71-86) and the first
 // pass of the reference's outer loop.  false = the walk is over before it
 // starts (the ray misses the box): the result is a miss.
-__device__ __forceinline__ bool walk_begin(const TravScene &P, Walk &w)
+__device__ __forceinline__ bool walk_begin(const TravScene &P, Walk &w, f3 o, f3 d)
 {
     float scene_t_min = 0.f;
     w.scene_t_max = RT_INF;
-    f3 inv = mk3(1 / w.d.x, 1 / w.d.y, 1 / w.d.z);
-    f3 t0 = (P.smin - w.o) * inv, t1 = (P.smax - w.o) * inv;
+    f3 inv = mk3(1 / d.x, 1 / d.y, 1 / d.z);
+    f3 t0 = (P.smin - o) * inv, t1 = (P.smax - o) * inv;
     f3 sm = mk3(cl_min(t0.x, t1.x), cl_min(t0.y, t1.y), cl_min(t0.z, t1.z));
     f3 bg = mk3(cl_max(t0.x, t1.x), cl_max(t0.y, t1.y), cl_max(t0.z, t1.z));
     scene_t_min = cl_max(scene_t_min, cl_max(sm.x, cl_max(sm.y, sm.z)));
@@ -215,14 +205,16 @@ __device__ __forceinline__ bool walk_begin(const TravScene &P, Walk &w)
 // branch (lanes with nothing to fetch read element 0, one shared cache line)
 // and pinned with an empty asm: left alone, the compiler sinks each load into
 // the branch that uses it and the wave then waits for memory twice per trip.
+// Byte offsets are 32-bit (the host checks both arrays stay below 4 GiB), which
+// keeps the address arithmetic to one shift / one multiply per load.
 __device__ __forceinline__ void walk_fetch(const TravScene &P, const Walk &w, bool walking, uint4 &node, float4 &T0,
                                            float4 &T1, float4 &T2)
 {
     const bool at_leaf = (w.ref & RT_REF_LEAF) != 0;
     const uint32_t nidx = (walking && !at_leaf) ? w.ref : 0u;
     const uint32_t tslot = (walking && at_leaf && w.li < w.lc) ? w.slot + w.li : 0u;
-    node = *(const uint4 *)((const char *)P.nodes + ((size_t)nidx << 4));
-    const float4 *tp = (const float4 *)((const char *)P.leaf_tris + (size_t)tslot * 48u);
+    node = *(const uint4 *)((const char *)P.nodes + (nidx << 4));
+    const float4 *tp = (const float4 *)((const char *)P.leaf_tris + tslot * 48u);
     T0 = tp[0]; T1 = tp[1]; T2 = tp[2];
     asm volatile("" : "+v"(node.x), "+v"(node.y), "+v"(node.z), "+v"(node.w),
                       "+v"(T0.x), "+v"(T0.y), "+v"(T0.z), "+v"(T0.w),
@@ -233,9 +225,9 @@ __device__ __forceinline__ void walk_fetch(const TravScene &P, const Walk &w, bo
 // One step of a walking lane; true when the walk has ended (w.t_hit etc. hold
 // the result, t_hit = +inf for a miss).
 template <int LDS_DEPTH>
-__device__ __forceinline__ bool walk_step(const TravScene &P, Walk &w, const uint4 &node, const float4 &T0,
-                                          const float4 &T1, const float4 &T2, uint2 *__restrict__ col,
-                                          uint2 *__restrict__ spill)
+__device__ __forceinline__ bool walk_step(const TravScene &P, Walk &w, f3 o, f3 d, const uint4 &node,
+                                          const float4 &T0, const float4 &T1, const float4 &T2,
+                                          uint2 *__restrict__ col, uint2 *__restrict__ spill)
 {
     bool finished = false;
     if (!(w.ref & RT_REF_LEAF)) {
@@ -243,8 +235,8 @@ __device__ __forceinline__ bool walk_step(const TravScene &P, Walk &w, const uin
         // adds the masked-out zeros, which turns -0 into +0.
         const uint32_t k = node.y;
         const float b = __uint_as_float(node.x);
-        const float ok = pick_axis(w.o, k) + 0.0f;
-        const float dk = pick_axis(w.d, k) + 0.0f;
+        const float ok = ((k == 0) ? o.x : ((k == 1) ? o.y : o.z)) + 0.0f;
+        const float dk = ((k == 0) ? d.x : ((k == 1) ? d.y : d.z)) + 0.0f;
         const float t_split = (b - ok) / dk;
         const bool left_close = (ok < b) || (ok == b && dk <= 0);
         const uint32_t first = left_close ? node.z : node.w;
@@ -264,7 +256,7 @@ __device__ __forceinline__ bool walk_step(const TravScene &P, Walk &w, const uin
         if (w.li < w.lc) {
             if (w.li == 0 && w.lc == 31u) w.lc = __float_as_uint(T1.w);
             float t, u, v;
-            if (tri_hit_edges(xyz(T0), xyz(T1), xyz(T2), w.o, w.d, t, u, v)) {
+            if (tri_hit_edges(xyz(T0), xyz(T1), xyz(T2), o, d, t, u, v)) {
                 if (!(t <= 0) && t < w.t_hit) {
                     w.t_hit = t; w.hu = u; w.hv = v; w.tri_indx = __float_as_uint(T0.w);
                     if (w.t_hit < w.t_max) finished = true;
@@ -279,14 +271,20 @@ __device__ __forceinline__ bool walk_step(const TravScene &P, Walk &w, const uin
                 w.t_min = w.t_max; w.t_max = w.scene_t_max;
                 walk_enter(w, P.root_ref);
             } else {
+                // entry sp-1 is popped; the t_max that goes with it is the t_split of
+                // entry sp-2 (scene_t_max at the bottom).  LDS and spill levels are
+                // read on separate paths so each stays a plain ds_read / scratch_load.
                 w.sp--;
-                const uint2 e = (w.sp < (uint32_t)LDS_DEPTH) ? col[w.sp * 64] : spill[w.sp - LDS_DEPTH];
-                w.t_min = __uint_as_float(e.y);
-                if (w.sp == 0) w.t_max = w.scene_t_max;
-                else {
-                    const uint2 below = (w.sp - 1 < (uint32_t)LDS_DEPTH) ? col[(w.sp - 1) * 64] : spill[w.sp - 1 - LDS_DEPTH];
-                    w.t_max = __uint_as_float(below.y);
+                uint2 e, below = make_uint2(0u, __float_as_uint(w.scene_t_max));
+                if (w.sp < (uint32_t)LDS_DEPTH) {
+                    e = col[w.sp * 64];
+                    if (w.sp > 0) below = col[(w.sp - 1) * 64];
+                } else {
+                    e = spill[w.sp - LDS_DEPTH];
+                    below = (w.sp - 1 < (uint32_t)LDS_DEPTH) ? col[(LDS_DEPTH - 1) * 64] : spill[w.sp - 1 - LDS_DEPTH];
                 }
+                w.t_min = __uint_as_float(e.y);
+                w.t_max = __uint_as_float(below.y);
                 walk_enter(w, e.x);
             }
         }
@@ -343,6 +341,7 @@ __global__ __launch_bounds__(64) void k_kd_intersect(TravScene P, const float4 *
 
     WorkQueue q;
     Walk w = {};
+    f3 o = mk3(0.f, 0.f, 0.f), d = o;
     bool walking = false;
     uint32_t ridx = 0;
 
@@ -353,9 +352,9 @@ __global__ __launch_bounds__(64) void k_kd_intersect(TravScene P, const float4 *
             const uint32_t mine = queue_take<CHUNK>(q, !walking, n, counter);
             if (mine != ~0u) {
                 ridx = mine;
-                w.o = xyz(ray_o[ridx]);
-                w.d = xyz(ray_d[ridx]);
-                walking = walk_begin(P, w);
+                o = xyz(ray_o[ridx]);
+                d = xyz(ray_d[ridx]);
+                walking = walk_begin(P, w, o, d);
                 if (!walking) hits[ridx] = walk_result(w);
             }
         }
@@ -365,7 +364,7 @@ __global__ __launch_bounds__(64) void k_kd_intersect(TravScene P, const float4 *
         }
         uint4 node; float4 T0, T1, T2;
         walk_fetch(P, w, walking, node, T0, T1, T2);
-        if (walking && walk_step<LDS_DEPTH>(P, w, node, T0, T1, T2, col, spill)) {
+        if (walking && walk_step<LDS_DEPTH>(P, w, o, d, node, T0, T1, T2, col, spill)) {
             hits[ridx] = walk_result(w);
             walking = false;
         }
@@ -587,6 +586,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, RT_RUN_WA
     enum { FREE = 0, WALK = 1, DONE = 2 };
     WorkQueue q;
     Walk w = {};
+    f3 o = mk3(0.f, 0.f, 0.f), d = o;
     uint32_t mode = FREE, pix = 0, it = 0, rnd = 0, steps = 0;
     float4 pa = make_float4(0, 0, 0, 0), pb = pa;
 
@@ -602,17 +602,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, RT_RUN_WA
                 const Hit h = walk_result(w);
                 rnd = ((rnd << 1) | (rnd >> 31)) + 1;                 // xorshift_batch
                 if (__float_as_uint(pa.w) == 2048u) {                 // reference: path.cl:145-152
-                    w.o = mk3(0.f, 0.f, 0.f); w.d = mk3(0.f, 0.f, 0.f);
+                    o = mk3(0.f, 0.f, 0.f); d = mk3(0.f, 0.f, 0.f);
                 } else {
                     f3 no, nd;
-                    spath_step(B.tri_shade, h, w.o, w.d, rnd, rv[it], pix, B.out_tex, B.origin_o, B.origin_d,
+                    spath_step(B.tri_shade, h, o, d, rnd, rv[it], pix, B.out_tex, B.origin_o, B.origin_d,
                                B.source_hits, pa, pb, no, nd);
-                    w.o = no; w.d = nd;
+                    o = no; d = nd;
                 }
                 it++;
                 if (it == iters) {       // leave the buffers as the last per-iteration launches would
-                    B.ray_o[pix] = mk4(w.o, 0.f);
-                    B.ray_d[pix] = mk4(w.d, 0.f);
+                    B.ray_o[pix] = mk4(o, 0.f);
+                    B.ray_d[pix] = mk4(d, 0.f);
                     B.prog_a[pix] = pa;
                     B.prog_b[pix] = pb;
                     B.random[pix] = rnd;
@@ -628,8 +628,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, RT_RUN_WA
             if (mine != ~0u) {
                 pix = B.order ? B.order[mine] : mine;
                 steps = 0;
-                w.o = xyz(B.ray_o[pix]);
-                w.d = xyz(B.ray_d[pix]);
+                o = xyz(B.ray_o[pix]);
+                d = xyz(B.ray_d[pix]);
                 pa = B.prog_a[pix];
                 pb = B.prog_b[pix];
                 rnd = B.random[pix];
@@ -637,7 +637,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, RT_RUN_WA
                 fresh = true;
             }
             // (c) start the walk of every new ray
-            if (fresh) mode = walk_begin(P, w) ? WALK : DONE;
+            if (fresh) mode = walk_begin(P, w, o, d) ? WALK : DONE;
         }
         if (!__any(mode == WALK)) {
             if (q.exhausted && !__any(mode == DONE)) break;
@@ -647,7 +647,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, RT_RUN_WA
         walk_fetch(P, w, mode == WALK, node, T0, T1, T2);
         if (mode == WALK) {
             steps++;
-            if (walk_step<LDS_DEPTH>(P, w, node, T0, T1, T2, col, spill)) mode = DONE;
+            if (walk_step<LDS_DEPTH>(P, w, o, d, node, T0, T1, T2, col, spill)) mode = DONE;
         }
     }
 }
