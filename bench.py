@@ -55,34 +55,35 @@ def make_scene(spec):
     return scenes.soup_scene(arg)
 
 
-def cpu_baseline(rt, sc, r, width, full_height, threads, target_rays=3_000_000):
-    """Oracle (C restatement, OpenMP) on a bounded sample: a strip of rows
-    around the middle of the same frame, same scene and RNG streams; prepass
-    untimed, then timed iterations.  Uses the serialised tree the library
-    produced (the reference's wire format) so no second tree build is needed."""
+def cpu_baseline(rt, sc, r, width, full_height, threads, budget_s=12.0, max_iters=96):
+    """Oracle (C restatement, OpenMP) on a bounded sample of the same workload:
+    the same frame, scene and RNG streams, prepass and the first (null-ray)
+    iteration untimed, then whole iterations until about `budget_s` seconds of
+    CPU work are spent.  Uses the serialised tree the library produced (the
+    reference's wire format), so no second tree build is needed."""
     import oracle
     from raytracer_amd.scenes import splitmix32
     kdt = r.kdt
     blob = np.ctypeslib.as_array(kdt.buffer, shape=(int(kdt.buffer_size),))
     tree = oracle.KdTree.from_blob(blob, sc.verts4, sc.idx4, kdt.bounds.min[:3], kdt.bounds.max[:3])
-    iters = 6
-    rows = max(1, min(full_height, target_rays // (width * iters)))
-    y0 = (full_height - rows) // 2
-    st = oracle.SpathState(sc, tree, width, rows, y0, full_height)
+    st = oracle.SpathState(sc, tree, width, full_height, 0, full_height)
     st.nthreads = threads
-    first = y0 * width
-    rb = splitmix32(1, np.arange(first, first + width * rows, dtype=np.uint64))
-    rv = splitmix32(2, np.arange(iters + 1, dtype=np.uint64))
+    rb = splitmix32(1, np.arange(width * full_height, dtype=np.uint64))
+    rv = splitmix32(2, np.arange(max_iters + 2, dtype=np.uint64))
     st.prepass(rb, int(rv[0]))
     st.iterate(int(rv[1]))             # the first iteration traces the wiped (null) rays: untimed
+    done = 0
     t0 = time.perf_counter()
-    for k in range(1, iters):
-        st.iterate(int(rv[k + 1]))
-    dt = time.perf_counter() - t0
-    rays = width * rows * (iters - 1)
+    while done < max_iters:
+        st.iterate(int(rv[done + 2]))
+        done += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s:
+            break
+    rays = width * full_height * done
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": f"rows {y0}..{y0 + rows - 1} of the {width}x{full_height} frame, {iters - 1} iterations "
-                      f"({rays} rays, {dt:.1f} s), oracle/oracle_rt.c with OpenMP"}
+            "sample": f"iterations 2..{done + 1} of the same {width}x{full_height} workload "
+                      f"({rays} rays, {dt:.1f} s), oracle/oracle_rt.c with OpenMP on {threads} threads"}
 
 
 def gather_stats(rt, sc, r, threads, sample=262_144):
@@ -110,7 +111,7 @@ def gather_stats(rt, sc, r, threads, sample=262_144):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--workload", default=os.environ.get("RT_BENCH_WORKLOAD", "c3"), choices=sorted(WORKLOADS))
     ap.add_argument("--separate-kernels", action="store_true", help="three launches per iteration, as the reference")
@@ -119,6 +120,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
+
+    # The library reports scene/tree progress on stdout like the reference does;
+    # keep stdout for the one JSON line and send everything else to stderr.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -206,11 +213,12 @@ def main():
         iters_per_launch = args.steps / max(launches, 1)      # 1 with --separate-kernels
         rays_per_launch = n_local * iters_per_launch
         achieved = (b_ray * rays_per_launch) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic = None
+        traffic = None                 # HBM bytes per launch from the PMC passes (profiles/pmc_passes.sh), if recorded
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(f"{args.workload}:{kname}")
+                per_iter = json.load(open(tpath))[f"{args.workload}:{kname}"]["hbm_bytes_per_iteration"]
+                traffic = round(per_iter * iters_per_launch * n_local / (width * height))
             except Exception:
                 traffic = None
         out = {
@@ -232,7 +240,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(rt, sc, r, width, height, threads)
             out["cpu_baseline"]["value"] = round(out["cpu_baseline"]["value"], 3)
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
 
     if torch is not None:
         dist.barrier()

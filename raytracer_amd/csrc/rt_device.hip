@@ -59,7 +59,9 @@ void rt_device_close(rt_device *dev)
 void rt_device_get_props(rt_device *dev, rt_device_props *out)
 {
     memset(out, 0, sizeof *out);
-    strncpy(out->name, dev->props.name, sizeof(out->name) - 1);
+    // Some driver stacks leave the marketing name empty; the ISA name is always there.
+    const char *name = dev->props.name[0] ? dev->props.name : dev->props.gcnArchName;
+    strncpy(out->name, name, sizeof(out->name) - 1);
     out->compute_units = dev->props.multiProcessorCount;
     out->wave_size = dev->props.warpSize;
     out->max_waves_per_cu = dev->props.maxThreadsPerMultiProcessor / (dev->props.warpSize ? dev->props.warpSize : 64);

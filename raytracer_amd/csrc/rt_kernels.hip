@@ -222,74 +222,106 @@ __device__ __forceinline__ void walk_fetch(const TravScene &P, const Walk &w, bo
                       "+v"(T2.x), "+v"(T2.y), "+v"(T2.z));
 }
 
-// One step of a walking lane; true when the walk has ended (w.t_hit etc. hold
-// the result, t_hit = +inf for a miss).
+// One descend step of a lane standing on an interior node,
+// reference: src/kernels/kdtree.cl:229-260.  get_elem (:67-75) adds the
+// masked-out zeros, which turns -0 into +0.
+template <int LDS_DEPTH>
+__device__ __forceinline__ void walk_interior(Walk &w, f3 o, f3 d, const uint4 &node, uint2 *__restrict__ col,
+                                              uint2 *__restrict__ spill)
+{
+    const uint32_t k = node.y;
+    const float b = __uint_as_float(node.x);
+    const float ok = ((k == 0) ? o.x : ((k == 1) ? o.y : o.z)) + 0.0f;
+    const float dk = ((k == 0) ? d.x : ((k == 1) ? d.y : d.z)) + 0.0f;
+    const float t_split = (b - ok) / dk;
+    const bool left_close = (ok < b) || (ok == b && dk <= 0);
+    const uint32_t first = left_close ? node.z : node.w;
+    const uint32_t second = left_close ? node.w : node.z;
+    const bool c1 = (t_split > w.t_max || t_split <= 0);
+    const bool c2 = (t_split < w.t_min);
+    if (!c1 && !c2) {
+        const uint2 e = make_uint2(second, __float_as_uint(t_split));
+        if (w.sp < (uint32_t)LDS_DEPTH) col[w.sp * 64] = e;
+        else if (w.sp < RT_MAX_STACK) spill[w.sp - LDS_DEPTH] = e;
+        w.sp++;
+        w.t_max = t_split;
+    }
+    walk_enter(w, (c1 || !c2) ? first : second);
+}
+
+// One step of a lane standing in a leaf (src/kernels/kdtree.cl:263-302): test
+// the next triangle, and when the leaf is used up pop / restart / end.  true
+// when the walk has ended (w.t_hit etc. hold the result, +inf for a miss).
+template <int LDS_DEPTH>
+__device__ __forceinline__ bool walk_leaf(const TravScene &P, Walk &w, f3 o, f3 d, const float4 &T0, const float4 &T1,
+                                          const float4 &T2, uint2 *__restrict__ col, uint2 *__restrict__ spill)
+{
+    bool finished = false;
+    if (w.li < w.lc) {
+        if (w.li == 0 && w.lc == 31u) w.lc = __float_as_uint(T1.w);
+        float t, u, v;
+        if (tri_hit_edges(xyz(T0), xyz(T1), xyz(T2), o, d, t, u, v)) {
+            if (!(t <= 0) && t < w.t_hit) {
+                w.t_hit = t; w.hu = u; w.hv = v; w.tri_indx = __float_as_uint(T0.w);
+                if (w.t_hit < w.t_max) finished = true;
+            }
+        }
+        w.li++;
+    }
+    if (!finished && w.li >= w.lc) {
+        // leaf used up: the reference's outer loop test, then restart or pop
+        if ((P.root_ref & RT_REF_LEAF) || !(w.t_max < w.scene_t_max)) finished = true;
+        else if (w.sp == 0) {
+            w.t_min = w.t_max; w.t_max = w.scene_t_max;
+            walk_enter(w, P.root_ref);
+        } else {
+            // entry sp-1 is popped; the t_max that goes with it is the t_split of
+            // entry sp-2 (scene_t_max at the bottom).  LDS and spill levels are
+            // read on separate paths so each stays a plain ds_read / scratch_load.
+            w.sp--;
+            uint2 e, below = make_uint2(0u, __float_as_uint(w.scene_t_max));
+            if (w.sp < (uint32_t)LDS_DEPTH) {
+                e = col[w.sp * 64];
+                if (w.sp > 0) below = col[(w.sp - 1) * 64];
+            } else {
+                e = spill[w.sp - LDS_DEPTH];
+                below = (w.sp - 1 < (uint32_t)LDS_DEPTH) ? col[(LDS_DEPTH - 1) * 64] : spill[w.sp - 1 - LDS_DEPTH];
+            }
+            w.t_min = __uint_as_float(e.y);
+            w.t_max = __uint_as_float(below.y);
+            walk_enter(w, e.x);
+        }
+    }
+    return finished;
+}
+
+// One step of a walking lane, whichever kind of node it stands on.
 template <int LDS_DEPTH>
 __device__ __forceinline__ bool walk_step(const TravScene &P, Walk &w, f3 o, f3 d, const uint4 &node,
                                           const float4 &T0, const float4 &T1, const float4 &T2,
                                           uint2 *__restrict__ col, uint2 *__restrict__ spill)
 {
-    bool finished = false;
-    if (!(w.ref & RT_REF_LEAF)) {
-        // descend, reference: src/kernels/kdtree.cl:229-260.  get_elem (:67-75)
-        // adds the masked-out zeros, which turns -0 into +0.
-        const uint32_t k = node.y;
-        const float b = __uint_as_float(node.x);
-        const float ok = ((k == 0) ? o.x : ((k == 1) ? o.y : o.z)) + 0.0f;
-        const float dk = ((k == 0) ? d.x : ((k == 1) ? d.y : d.z)) + 0.0f;
-        const float t_split = (b - ok) / dk;
-        const bool left_close = (ok < b) || (ok == b && dk <= 0);
-        const uint32_t first = left_close ? node.z : node.w;
-        const uint32_t second = left_close ? node.w : node.z;
-        const bool c1 = (t_split > w.t_max || t_split <= 0);
-        const bool c2 = (t_split < w.t_min);
-        if (!c1 && !c2) {
-            const uint2 e = make_uint2(second, __float_as_uint(t_split));
-            if (w.sp < (uint32_t)LDS_DEPTH) col[w.sp * 64] = e;
-            else if (w.sp < RT_MAX_STACK) spill[w.sp - LDS_DEPTH] = e;
-            w.sp++;
-            w.t_max = t_split;
-        }
-        walk_enter(w, (c1 || !c2) ? first : second);
-    } else {
-        // leaf, reference: src/kernels/kdtree.cl:263-302
-        if (w.li < w.lc) {
-            if (w.li == 0 && w.lc == 31u) w.lc = __float_as_uint(T1.w);
-            float t, u, v;
-            if (tri_hit_edges(xyz(T0), xyz(T1), xyz(T2), o, d, t, u, v)) {
-                if (!(t <= 0) && t < w.t_hit) {
-                    w.t_hit = t; w.hu = u; w.hv = v; w.tri_indx = __float_as_uint(T0.w);
-                    if (w.t_hit < w.t_max) finished = true;
-                }
-            }
-            w.li++;
-        }
-        if (!finished && w.li >= w.lc) {
-            // leaf used up: the reference's outer loop test, then restart or pop
-            if ((P.root_ref & RT_REF_LEAF) || !(w.t_max < w.scene_t_max)) finished = true;
-            else if (w.sp == 0) {
-                w.t_min = w.t_max; w.t_max = w.scene_t_max;
-                walk_enter(w, P.root_ref);
-            } else {
-                // entry sp-1 is popped; the t_max that goes with it is the t_split of
-                // entry sp-2 (scene_t_max at the bottom).  LDS and spill levels are
-                // read on separate paths so each stays a plain ds_read / scratch_load.
-                w.sp--;
-                uint2 e, below = make_uint2(0u, __float_as_uint(w.scene_t_max));
-                if (w.sp < (uint32_t)LDS_DEPTH) {
-                    e = col[w.sp * 64];
-                    if (w.sp > 0) below = col[(w.sp - 1) * 64];
-                } else {
-                    e = spill[w.sp - LDS_DEPTH];
-                    below = (w.sp - 1 < (uint32_t)LDS_DEPTH) ? col[(LDS_DEPTH - 1) * 64] : spill[w.sp - 1 - LDS_DEPTH];
-                }
-                w.t_min = __uint_as_float(e.y);
-                w.t_max = __uint_as_float(below.y);
-                walk_enter(w, e.x);
-            }
-        }
-    }
-    return finished;
+    if (!(w.ref & RT_REF_LEAF)) { walk_interior<LDS_DEPTH>(w, o, d, node, col, spill); return false; }
+    return walk_leaf<LDS_DEPTH>(P, w, o, d, T0, T1, T2, col, spill);
+}
+
+// Single-kind fetches for trips that serve only one kind of lane.
+__device__ __forceinline__ void walk_fetch_node(const TravScene &P, const Walk &w, bool want, uint4 &node)
+{
+    const uint32_t nidx = want ? w.ref : 0u;
+    node = *(const uint4 *)((const char *)P.nodes + (nidx << 4));
+    asm volatile("" : "+v"(node.x), "+v"(node.y), "+v"(node.z), "+v"(node.w));
+}
+
+__device__ __forceinline__ void walk_fetch_tri(const TravScene &P, const Walk &w, bool want, float4 &T0, float4 &T1,
+                                               float4 &T2)
+{
+    const uint32_t tslot = (want && w.li < w.lc) ? w.slot + w.li : 0u;
+    const float4 *tp = (const float4 *)((const char *)P.leaf_tris + tslot * 48u);
+    T0 = tp[0]; T1 = tp[1]; T2 = tp[2];
+    asm volatile("" : "+v"(T0.x), "+v"(T0.y), "+v"(T0.z), "+v"(T0.w),
+                      "+v"(T1.x), "+v"(T1.y), "+v"(T1.z), "+v"(T1.w),
+                      "+v"(T2.x), "+v"(T2.y), "+v"(T2.z));
 }
 
 __device__ __forceinline__ Hit walk_result(const Walk &w)
@@ -562,6 +594,9 @@ __global__ void k_spath_trace(const float4 *__restrict__ tri_shade, float4 *__re
 #ifndef RT_RUN_WAVES_PER_EU
 #define RT_RUN_WAVES_PER_EU 5
 #endif
+#ifndef RT_RUN_MIN_WAVES_PER_EU
+#define RT_RUN_MIN_WAVES_PER_EU 1
+#endif
 
 struct SpathDev {
     const float4 *tri_shade;
@@ -575,8 +610,8 @@ struct SpathDev {
     const uint32_t *order;      // in: pixel to serve as j-th work item (nullptr = j)
 };
 
-template <int LDS_DEPTH, int SHADE_MIN, int CHUNK>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, RT_RUN_WAVES_PER_EU))) void k_spath_run(TravScene P, SpathDev B, uint32_t n, uint32_t iters,
+template <int LDS_DEPTH, int SHADE_MIN, int CHUNK, int NI, int NT>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_RUN_MIN_WAVES_PER_EU, RT_RUN_WAVES_PER_EU))) void k_spath_run(TravScene P, SpathDev B, uint32_t n, uint32_t iters,
                                                   const uint32_t *__restrict__ rv, uint32_t *__restrict__ counter)
 {
     __shared__ uint2 stack[LDS_DEPTH * 64];
@@ -643,11 +678,38 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, RT_RUN_WA
             if (q.exhausted && !__any(mode == DONE)) break;
             continue;
         }
-        uint4 node; float4 T0, T1, T2;
-        walk_fetch(P, w, mode == WALK, node, T0, T1, T2);
-        if (mode == WALK) {
-            steps++;
-            if (walk_step<LDS_DEPTH>(P, w, o, d, node, T0, T1, T2, col, spill)) mode = DONE;
+        if (NI == 0) {
+            // one step per lane per trip, both kinds of node fetched together
+            uint4 node; float4 T0, T1, T2;
+            walk_fetch(P, w, mode == WALK, node, T0, T1, T2);
+            if (mode == WALK) {
+                steps++;
+                if (walk_step<LDS_DEPTH>(P, w, o, d, node, T0, T1, T2, col, spill)) mode = DONE;
+            }
+        } else {
+            // up to NI descend steps, then up to NT leaf steps: a lane that reaches
+            // its leaf within the trip tests its triangles in the same trip
+#pragma unroll
+            for (int r = 0; r < NI; r++) {
+                const bool interior = mode == WALK && !(w.ref & RT_REF_LEAF);
+                if (__any(interior)) {
+                    uint4 node;
+                    walk_fetch_node(P, w, interior, node);
+                    if (interior) { steps++; walk_interior<LDS_DEPTH>(w, o, d, node, col, spill); }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < NT; r++) {
+                const bool leaf = mode == WALK && (w.ref & RT_REF_LEAF);
+                if (__any(leaf)) {
+                    float4 T0, T1, T2;
+                    walk_fetch_tri(P, w, leaf, T0, T1, T2);
+                    if (leaf) {
+                        steps++;
+                        if (walk_leaf<LDS_DEPTH>(P, w, o, d, T0, T1, T2, col, spill)) mode = DONE;
+                    }
+                }
+            }
         }
     }
 }
@@ -1045,11 +1107,11 @@ void launch_kd_intersect(rt_device *dev, const TravScene &P, const float4 *ro, c
 }
 
 
-template <int LDS_DEPTH, int SHADE_MIN, int CHUNK>
+template <int LDS_DEPTH, int SHADE_MIN, int CHUNK, int NI, int NT>
 void launch_run_variant(rt_device *dev, const TravScene &P, const SpathDev &B, uint32_t n, uint32_t iters,
                         const uint32_t *rv)
 {
-    auto kern = k_spath_run<LDS_DEPTH, SHADE_MIN, CHUNK>;
+    auto kern = k_spath_run<LDS_DEPTH, SHADE_MIN, CHUNK, NI, NT>;
     static int blocks_per_cu = 0;
     if (!blocks_per_cu) {
         RT_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kern, 64, 0));
@@ -1073,12 +1135,13 @@ void launch_spath_run(rt_device *dev, const TravScene &P, const SpathDev &B, uin
         variant = e ? atoi(e) : 0;
     }
     switch (variant) {
-    case 1: launch_run_variant<12, 16, 256>(dev, P, B, n, iters, rv); break;
-    case 2: launch_run_variant<12, 32, 256>(dev, P, B, n, iters, rv); break;
-    case 3: launch_run_variant<16, 24, 256>(dev, P, B, n, iters, rv); break;
-    case 4: launch_run_variant<12, 8, 256>(dev, P, B, n, iters, rv); break;
-    case 5: launch_run_variant<8, 24, 256>(dev, P, B, n, iters, rv); break;
-    default: launch_run_variant<12, 24, 256>(dev, P, B, n, iters, rv); break;
+    case 1: launch_run_variant<12, 16, 256, 1, 1>(dev, P, B, n, iters, rv); break;
+    case 2: launch_run_variant<12, 16, 256, 2, 1>(dev, P, B, n, iters, rv); break;
+    case 3: launch_run_variant<12, 16, 256, 2, 2>(dev, P, B, n, iters, rv); break;
+    case 4: launch_run_variant<12, 16, 256, 3, 1>(dev, P, B, n, iters, rv); break;
+    case 5: launch_run_variant<12, 16, 256, 0, 0>(dev, P, B, n, iters, rv); break;
+    case 6: launch_run_variant<12, 16, 256, 4, 2>(dev, P, B, n, iters, rv); break;
+    default: launch_run_variant<12, 16, 256, 3, 2>(dev, P, B, n, iters, rv); break;
     }
 }
 
