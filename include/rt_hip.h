@@ -166,9 +166,13 @@ void rt_k_spath_run(rt_device *dev, const rt_kd_view *kd, const rt_spath_buffers
                     rt_mem random_values, rt_mem cost, rt_mem order);
 
 /* Pixel indices sorted by decreasing cost >> shift (counting sort, 256 buckets)
-   into order[0..n); hist256 is 256 words of scratch.  No counterpart in the
-   reference: it only feeds the scheduling of the next rt_k_spath_run. */
-void rt_k_pixel_order(rt_device *dev, rt_mem cost, rt_mem order, rt_mem hist256, uint32_t n, uint32_t shift);
+   into order[0..n); hist256 is 256 words of scratch.  Pixels of equal bucket
+   keep screen-tile order (8x8 tiles of a frame `width` pixels wide) when width
+   and n / width are multiples of 8, index order otherwise (width 0: always).
+   No counterpart in the reference: it only feeds the scheduling of the next
+   rt_k_spath_run. */
+void rt_k_pixel_order(rt_device *dev, rt_mem cost, rt_mem order, rt_mem hist256, uint32_t n, uint32_t shift,
+                      uint32_t width);
 
 /* f_buffer_to_byte_buffer_avg (src/kernels/path.cl:428-444; host src/spath_raytracer.c:252-277). */
 void rt_k_resolve_avg(rt_device *dev, rt_mem out_u32, rt_mem out_tex, uint32_t n);

@@ -246,7 +246,7 @@ def lib():
     L.rt_k_spath_trace.argtypes = [vp, C.POINTER(rt_kd_view), C.POINTER(rt_spath_buffers), u32, u32, C.c_int]
     L.rt_k_xorshift.argtypes = [vp, vp, u32]
     L.rt_k_spath_run.argtypes = [vp, C.POINTER(rt_kd_view), C.POINTER(rt_spath_buffers), u32, u32, vp, vp, vp]
-    L.rt_k_pixel_order.argtypes = [vp, vp, vp, vp, u32, u32]
+    L.rt_k_pixel_order.argtypes = [vp, vp, vp, vp, u32, u32, u32]
     L.rt_k_resolve_avg.argtypes = [vp, vp, vp, u32]
     L.rt_k_f_buffer_average.argtypes = [vp, vp, vp, u32, u32]
     L.rt_k_f_to_byte.argtypes = [vp, vp, vp, u32]

@@ -112,6 +112,13 @@ void spath_raytracer_flush(spath_raytracer_context *c)
     /* blocking upload: also orders this batch behind the previous one, so the
        table is not overwritten while a launch still reads it */
     rt_mem_upload(dev, c->cl_random_value_buffer, c->pending_values, sizeof(unsigned int) * c->pending);
+    if (!c->order_valid && !c->no_reorder && n >= 65536) {
+        /* nothing is known about costs yet: all pixels in one bucket, i.e. plain screen-tile order */
+        rt_mem_zero(dev, c->cl_pixel_cost_buffer, sizeof(unsigned int) * (size_t)n);
+        rt_k_pixel_order(dev, c->cl_pixel_cost_buffer, c->cl_pixel_order_buffer, c->cl_cost_hist_buffer, n, 0,
+                         rctx->width);
+        c->order_valid = true;
+    }
     rt_k_spath_run(dev, &rctx->stat_scene->kdt->view, &b, n, c->pending, c->cl_random_value_buffer,
                    c->cl_pixel_cost_buffer, (c->order_valid && !c->no_reorder) ? c->cl_pixel_order_buffer : NULL);
     if (!c->no_reorder && n >= 65536) {
@@ -119,7 +126,8 @@ void spath_raytracer_flush(spath_raytracer_context *c)
            bucket width ~ 1/64 of a typical pixel's cost (about 32 steps per iteration) */
         unsigned int shift = 0;
         while ((32u * c->pending) >> shift > 64u) shift++;
-        rt_k_pixel_order(dev, c->cl_pixel_cost_buffer, c->cl_pixel_order_buffer, c->cl_cost_hist_buffer, n, shift);
+        rt_k_pixel_order(dev, c->cl_pixel_cost_buffer, c->cl_pixel_order_buffer, c->cl_cost_hist_buffer, n, shift,
+                         rctx->width);
         c->order_valid = true;
     }
     c->pending = 0;

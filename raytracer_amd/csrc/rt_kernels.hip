@@ -295,6 +295,20 @@ __device__ __forceinline__ bool walk_leaf(const TravScene &P, Walk &w, f3 o, f3 
     return finished;
 }
 
+// walk_leaf for callers that have not fetched the triangle: loads it only when
+// there is one to test.
+template <int LDS_DEPTH>
+__device__ __forceinline__ bool walk_leaf_load(const TravScene &P, Walk &w, f3 o, f3 d, uint2 *__restrict__ col,
+                                               uint2 *__restrict__ spill)
+{
+    float4 T0 = make_float4(0, 0, 0, 0), T1 = T0, T2 = T0;
+    if (w.li < w.lc) {
+        const float4 *tp = (const float4 *)((const char *)P.leaf_tris + (w.slot + w.li) * 48u);
+        T0 = tp[0]; T1 = tp[1]; T2 = tp[2];
+    }
+    return walk_leaf<LDS_DEPTH>(P, w, o, d, T0, T1, T2, col, spill);
+}
+
 // One step of a walking lane, whichever kind of node it stands on.
 template <int LDS_DEPTH>
 __device__ __forceinline__ bool walk_step(const TravScene &P, Walk &w, f3 o, f3 d, const uint4 &node,
@@ -305,23 +319,12 @@ __device__ __forceinline__ bool walk_step(const TravScene &P, Walk &w, f3 o, f3 
     return walk_leaf<LDS_DEPTH>(P, w, o, d, T0, T1, T2, col, spill);
 }
 
-// Single-kind fetches for trips that serve only one kind of lane.
-__device__ __forceinline__ void walk_fetch_node(const TravScene &P, const Walk &w, bool want, uint4 &node)
+// Single-kind fetches for the slots of a trip that serve only one kind of lane;
+// called by those lanes only (the loads are exec-masked, idle lanes cost the
+// cache nothing).
+__device__ __forceinline__ uint4 walk_load_node(const TravScene &P, const Walk &w)
 {
-    const uint32_t nidx = want ? w.ref : 0u;
-    node = *(const uint4 *)((const char *)P.nodes + (nidx << 4));
-    asm volatile("" : "+v"(node.x), "+v"(node.y), "+v"(node.z), "+v"(node.w));
-}
-
-__device__ __forceinline__ void walk_fetch_tri(const TravScene &P, const Walk &w, bool want, float4 &T0, float4 &T1,
-                                               float4 &T2)
-{
-    const uint32_t tslot = (want && w.li < w.lc) ? w.slot + w.li : 0u;
-    const float4 *tp = (const float4 *)((const char *)P.leaf_tris + tslot * 48u);
-    T0 = tp[0]; T1 = tp[1]; T2 = tp[2];
-    asm volatile("" : "+v"(T0.x), "+v"(T0.y), "+v"(T0.z), "+v"(T0.w),
-                      "+v"(T1.x), "+v"(T1.y), "+v"(T1.z), "+v"(T1.w),
-                      "+v"(T2.x), "+v"(T2.y), "+v"(T2.z));
+    return *(const uint4 *)((const char *)P.nodes + (w.ref << 4));
 }
 
 __device__ __forceinline__ Hit walk_result(const Walk &w)
@@ -346,6 +349,16 @@ __device__ __forceinline__ uint32_t queue_take(WorkQueue &q, bool want, uint32_t
     const unsigned long long mask = __ballot(want);
     const uint32_t nwant = (uint32_t)__popcll(mask);
     if (q.exhausted || nwant == 0) return ~0u;
+    if (CHUNK == 0) {
+        // claim exactly what the wave needs now
+        uint32_t base = 0;
+        if (threadIdx.x == 0) base = atomicAdd(counter, nwant);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if (base >= n) { q.exhausted = true; return ~0u; }
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+        if (n - base <= nwant) q.exhausted = true;
+        return (want && rank < n - base) ? base + rank : ~0u;
+    }
     if (q.next >= q.end) {
         uint32_t base = 0;
         if (threadIdx.x == 0) base = atomicAdd(counter, (uint32_t)CHUNK);
@@ -610,8 +623,8 @@ struct SpathDev {
     const uint32_t *order;      // in: pixel to serve as j-th work item (nullptr = j)
 };
 
-template <int LDS_DEPTH, int SHADE_MIN, int CHUNK, int NI, int NT>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_RUN_MIN_WAVES_PER_EU, RT_RUN_WAVES_PER_EU))) void k_spath_run(TravScene P, SpathDev B, uint32_t n, uint32_t iters,
+template <int LDS_DEPTH, int SHADE_MIN, int CHUNK, int NI, int NT, int WAVES>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_spath_run(TravScene P, SpathDev B, uint32_t n, uint32_t iters,
                                                   const uint32_t *__restrict__ rv, uint32_t *__restrict__ counter)
 {
     __shared__ uint2 stack[LDS_DEPTH * 64];
@@ -692,22 +705,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_RUN_MIN_W
 #pragma unroll
             for (int r = 0; r < NI; r++) {
                 const bool interior = mode == WALK && !(w.ref & RT_REF_LEAF);
-                if (__any(interior)) {
-                    uint4 node;
-                    walk_fetch_node(P, w, interior, node);
-                    if (interior) { steps++; walk_interior<LDS_DEPTH>(w, o, d, node, col, spill); }
+                if (interior) {
+                    const uint4 node = walk_load_node(P, w);
+                    steps++;
+                    walk_interior<LDS_DEPTH>(w, o, d, node, col, spill);
                 }
             }
 #pragma unroll
             for (int r = 0; r < NT; r++) {
                 const bool leaf = mode == WALK && (w.ref & RT_REF_LEAF);
-                if (__any(leaf)) {
-                    float4 T0, T1, T2;
-                    walk_fetch_tri(P, w, leaf, T0, T1, T2);
-                    if (leaf) {
-                        steps++;
-                        if (walk_leaf<LDS_DEPTH>(P, w, o, d, T0, T1, T2, col, spill)) mode = DONE;
-                    }
+                if (leaf) {
+                    steps++;
+                    if (walk_leaf_load<LDS_DEPTH>(P, w, o, d, col, spill)) mode = DONE;
                 }
             }
         }
@@ -731,14 +740,26 @@ __device__ __forceinline__ uint32_t cost_bucket(uint32_t c, uint32_t shift)
     return (RT_COST_BUCKETS - 1) - (b < RT_COST_BUCKETS - 1 ? b : RT_COST_BUCKETS - 1);   // heaviest -> bucket 0
 }
 
+// The sort visits the pixels tile by tile (8x8 pixels, tiles in rows) when the
+// frame allows it, so pixels of one bucket that end up next to each other in
+// the order are also neighbours on screen: a wave's rays then share nodes and
+// triangles.  tiles_per_row == 0: plain index order.
+__device__ __forceinline__ uint32_t tile_pixel(uint32_t i, uint32_t tiles_per_row)
+{
+    if (tiles_per_row == 0) return i;
+    const uint32_t tile = i >> 6, in = i & 63u;
+    const uint32_t tx = tile % tiles_per_row, ty = tile / tiles_per_row;
+    return (ty * 8u + (in >> 3)) * (tiles_per_row * 8u) + tx * 8u + (in & 7u);
+}
+
 __global__ __launch_bounds__(256) void k_cost_hist(const uint32_t *__restrict__ cost, uint32_t n, uint32_t shift,
-                                                    uint32_t *__restrict__ hist)
+                                                    uint32_t tiles_per_row, uint32_t *__restrict__ hist)
 {
     __shared__ uint32_t local[RT_COST_BUCKETS];
     local[threadIdx.x] = 0;
     __syncthreads();
     for (uint32_t i = blockIdx.x * 1024u + threadIdx.x, e = min(n, (blockIdx.x + 1u) * 1024u); i < e; i += 256u)
-        atomicAdd(&local[cost_bucket(cost[i], shift)], 1u);
+        atomicAdd(&local[cost_bucket(cost[tile_pixel(i, tiles_per_row)], shift)], 1u);
     __syncthreads();
     if (local[threadIdx.x]) atomicAdd(&hist[threadIdx.x], local[threadIdx.x]);
 }
@@ -758,7 +779,8 @@ __global__ __launch_bounds__(256) void k_cost_scan(uint32_t *__restrict__ hist)
 }
 
 __global__ __launch_bounds__(256) void k_cost_scatter(const uint32_t *__restrict__ cost, uint32_t n, uint32_t shift,
-                                                       uint32_t *__restrict__ next, uint32_t *__restrict__ order)
+                                                       uint32_t tiles_per_row, uint32_t *__restrict__ next,
+                                                       uint32_t *__restrict__ order)
 {
     __shared__ uint32_t local[RT_COST_BUCKETS], base[RT_COST_BUCKETS];
     local[threadIdx.x] = 0;
@@ -767,7 +789,7 @@ __global__ __launch_bounds__(256) void k_cost_scatter(const uint32_t *__restrict
     const uint32_t first = blockIdx.x * 1024u + threadIdx.x;
     for (int k = 0; k < 4; k++) {
         const uint32_t i = first + 256u * k;
-        bucket[k] = (i < n) ? cost_bucket(cost[i], shift) : 0u;
+        bucket[k] = (i < n) ? cost_bucket(cost[tile_pixel(i, tiles_per_row)], shift) : 0u;
         rank[k] = (i < n) ? atomicAdd(&local[bucket[k]], 1u) : 0u;
     }
     __syncthreads();
@@ -775,7 +797,7 @@ __global__ __launch_bounds__(256) void k_cost_scatter(const uint32_t *__restrict
     __syncthreads();
     for (int k = 0; k < 4; k++) {
         const uint32_t i = first + 256u * k;
-        if (i < n) order[base[bucket[k]] + rank[k]] = i;
+        if (i < n) order[base[bucket[k]] + rank[k]] = tile_pixel(i, tiles_per_row);
     }
 }
 
@@ -1107,15 +1129,16 @@ void launch_kd_intersect(rt_device *dev, const TravScene &P, const float4 *ro, c
 }
 
 
-template <int LDS_DEPTH, int SHADE_MIN, int CHUNK, int NI, int NT>
+template <int LDS_DEPTH, int SHADE_MIN, int CHUNK, int NI, int NT, int WAVES>
 void launch_run_variant(rt_device *dev, const TravScene &P, const SpathDev &B, uint32_t n, uint32_t iters,
                         const uint32_t *rv)
 {
-    auto kern = k_spath_run<LDS_DEPTH, SHADE_MIN, CHUNK, NI, NT>;
+    auto kern = k_spath_run<LDS_DEPTH, SHADE_MIN, CHUNK, NI, NT, WAVES>;
     static int blocks_per_cu = 0;
     if (!blocks_per_cu) {
         RT_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kern, 64, 0));
         if (blocks_per_cu < 1) blocks_per_cu = 1;
+        if (getenv("RT_VERBOSE")) fprintf(stderr, "[rt] render kernel: %d waves per CU\n", blocks_per_cu);
     }
     unsigned grid = (unsigned)blocks_per_cu * (unsigned)dev->props.multiProcessorCount;
     const unsigned need = blocks_for(n, 64);
@@ -1135,13 +1158,16 @@ void launch_spath_run(rt_device *dev, const TravScene &P, const SpathDev &B, uin
         variant = e ? atoi(e) : 0;
     }
     switch (variant) {
-    case 1: launch_run_variant<12, 16, 256, 1, 1>(dev, P, B, n, iters, rv); break;
-    case 2: launch_run_variant<12, 16, 256, 2, 1>(dev, P, B, n, iters, rv); break;
-    case 3: launch_run_variant<12, 16, 256, 2, 2>(dev, P, B, n, iters, rv); break;
-    case 4: launch_run_variant<12, 16, 256, 3, 1>(dev, P, B, n, iters, rv); break;
-    case 5: launch_run_variant<12, 16, 256, 0, 0>(dev, P, B, n, iters, rv); break;
-    case 6: launch_run_variant<12, 16, 256, 4, 2>(dev, P, B, n, iters, rv); break;
-    default: launch_run_variant<12, 16, 256, 3, 2>(dev, P, B, n, iters, rv); break;
+    case 1: launch_run_variant<12, 16, 64, 2, 1, 6>(dev, P, B, n, iters, rv); break;
+    case 2: launch_run_variant<12, 16, 0, 2, 1, 6>(dev, P, B, n, iters, rv); break;
+    case 3: launch_run_variant<10, 16, 0, 2, 1, 7>(dev, P, B, n, iters, rv); break;
+    case 4: launch_run_variant<10, 16, 64, 2, 1, 7>(dev, P, B, n, iters, rv); break;
+    case 5: launch_run_variant<10, 24, 64, 2, 1, 7>(dev, P, B, n, iters, rv); break;
+    case 6: launch_run_variant<10, 16, 64, 3, 1, 7>(dev, P, B, n, iters, rv); break;
+    case 7: launch_run_variant<10, 16, 64, 1, 1, 7>(dev, P, B, n, iters, rv); break;
+    case 8: launch_run_variant<12, 16, 64, 3, 2, 5>(dev, P, B, n, iters, rv); break;
+    case 9: launch_run_variant<10, 8, 64, 2, 1, 7>(dev, P, B, n, iters, rv); break;
+    default: launch_run_variant<10, 16, 64, 2, 1, 7>(dev, P, B, n, iters, rv); break;
     }
 }
 
@@ -1211,16 +1237,19 @@ void rt_k_xorshift(rt_device *dev, rt_mem random, uint32_t n)
     RT_AFTER_LAUNCH();
 }
 
-void rt_k_pixel_order(rt_device *dev, rt_mem cost, rt_mem order, rt_mem hist256, uint32_t n, uint32_t shift)
+void rt_k_pixel_order(rt_device *dev, rt_mem cost, rt_mem order, rt_mem hist256, uint32_t n, uint32_t shift,
+                      uint32_t width)
 {
     if (!n) return;
+    uint32_t tiles_per_row = 0;
+    if (width && width % 8u == 0 && n % width == 0 && (n / width) % 8u == 0) tiles_per_row = width / 8u;
     rt_launch_timer tm(dev, RT_K_PIXEL_ORDER);
     RT_HIP_CHECK(hipMemsetAsync(hist256, 0, RT_COST_BUCKETS * sizeof(uint32_t), dev->stream));
     hipLaunchKernelGGL(k_cost_hist, dim3(blocks_for(n, 1024)), dim3(256), 0, dev->stream, (const uint32_t *)cost, n,
-                       shift, (uint32_t *)hist256);
+                       shift, tiles_per_row, (uint32_t *)hist256);
     hipLaunchKernelGGL(k_cost_scan, dim3(1), dim3(256), 0, dev->stream, (uint32_t *)hist256);
     hipLaunchKernelGGL(k_cost_scatter, dim3(blocks_for(n, 1024)), dim3(256), 0, dev->stream, (const uint32_t *)cost, n,
-                       shift, (uint32_t *)hist256, (uint32_t *)order);
+                       shift, tiles_per_row, (uint32_t *)hist256, (uint32_t *)order);
     RT_AFTER_LAUNCH();
 }
 
