@@ -112,7 +112,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--workload", default=os.environ.get("RT_BENCH_WORKLOAD", "c3"), choices=sorted(WORKLOADS))
     ap.add_argument("--separate-kernels", action="store_true", help="three launches per iteration, as the reference")
     ap.add_argument("--max-batch", type=int, default=None, help="most iterations folded into one launch")
