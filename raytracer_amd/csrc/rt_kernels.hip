@@ -600,16 +600,17 @@ __global__ void k_spath_trace(const float4 *__restrict__ tri_shade, float4 *__re
 // Shading is much heavier per call than a walk step, so lanes whose walk has
 // ended wait until SHADE_MIN of them can be served together (or nothing else is
 // left to do); the same service pass hands pixels to free lanes.
+//
+// Walk slots of a trip: NI descend slots, then NT leaf slots.  In each slot only
+// the lanes standing on that kind of node load and step (exec-masked, so idle
+// lanes cost the cache nothing); a lane that reaches its leaf in a descend slot
+// tests its first triangle in the same trip.  NI == 0 selects the older shape:
+// one step per lane per trip, node and triangle fetched together.
+//
+// WAVES is the occupancy the register allocation is held to (waves per SIMD):
+// waves spend more than half of their time waiting for gathers, so a seventh
+// wave is worth more than registers; at eight the path state spills.
 // ---------------------------------------------------------------------------
-// The kernel is VALU-issue bound, not latency bound: registers are worth more
-// than a sixth wave per SIMD (capping the allocation at 80 spills path state
-// into scratch inside the loop).
-#ifndef RT_RUN_WAVES_PER_EU
-#define RT_RUN_WAVES_PER_EU 5
-#endif
-#ifndef RT_RUN_MIN_WAVES_PER_EU
-#define RT_RUN_MIN_WAVES_PER_EU 1
-#endif
 
 struct SpathDev {
     const float4 *tri_shade;
