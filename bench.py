@@ -134,12 +134,20 @@ def main():
         log(f"note: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
     n_gpus = world
 
+    # RT_BENCH_FORCE_DIST=1 takes the multi-process path with a single rank, RT_BENCH_BACKEND=gloo and
+    # RT_BENCH_SHARE_GPU=1 let several ranks rehearse it on one GPU (RCCL refuses two ranks on one device).
     dist = torch = None
-    if world > 1:
+    backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
+    if os.environ.get("RT_BENCH_SHARE_GPU"):
+        local_rank = 0
+    if world > 1 or os.environ.get("RT_BENCH_FORCE_DIST"):
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     import raytracer_amd as rt
 
@@ -178,7 +186,8 @@ def main():
     frame = None
     if torch is not None:
         frame = torch.empty(n_local, dtype=torch.int32, device=f"cuda:{local_rank}")
-        gathered = [torch.empty_like(frame) for _ in range(world)] if rank == 0 else None
+        wire = frame if backend == "nccl" else torch.empty(n_local, dtype=torch.int32)    # gloo moves host tensors
+        gathered = [torch.empty_like(wire) for _ in range(world)] if rank == 0 else None
 
     sync_all()
     t0 = time.perf_counter()
@@ -188,11 +197,13 @@ def main():
         r.L.rt_k_resolve_avg(r.dev, r.rctx.contents.cl_output_buffer, r.spath.contents.cl_path_output_buffer, n_local)
         r.L.rt_mem_copy(r.dev, frame.data_ptr(), r.rctx.contents.cl_output_buffer, n_local * 4)
         r.sync()
-        dist.gather(frame, gathered, dst=0)
+        if wire is not frame:
+            wire.copy_(frame)
+        dist.gather(wire, gathered, dst=0)
     sync_all()
     dt = time.perf_counter() - t0
     if torch is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -202,6 +213,14 @@ def main():
     launches, kms = r.timing_get(kname)
     _, shade_ms = r.timing_get("spath_trace")
     r.timing(False)
+
+    # The image after warmup + steps iterations does not depend on how many GPUs rendered it:
+    # its checksum goes into the line so runs at different N can be compared.
+    import zlib
+    if torch is not None:
+        frame_crc = zlib.crc32(torch.cat(gathered).cpu().numpy().tobytes()) if rank == 0 else 0
+    else:
+        frame_crc = zlib.crc32(r.spath_resolve().tobytes())
 
     if rank == 0:
         total_rays = width * height * args.steps
@@ -227,7 +246,7 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {desc}", "triangles": int(sc.num_tris), "width": width,
-                       "height": height, "rows_per_gpu": strip, "kernel": kname,
+                       "height": height, "rows_per_gpu": strip, "kernel": kname, "frame_crc32": f"{frame_crc:08x}",
                        "partition": f"{world} row strips + RCCL gather of the resolved frame" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
