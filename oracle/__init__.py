@@ -66,6 +66,49 @@ def ref_lib():
     return _REF
 
 
+_REF_OBJ = None
+
+
+class _RefObj(C.Structure):
+    _fields_ = [("vertices", C.POINTER(C.c_float)), ("normals", C.POINTER(C.c_float)),
+                ("texcoords", C.POINTER(C.c_float)),
+                ("num_vertices", C.c_uint), ("num_normals", C.c_uint), ("num_texcoords", C.c_uint),
+                ("faces", C.POINTER(C.c_int)), ("num_faces", C.c_uint),
+                ("face_num_verts", C.POINTER(C.c_int)), ("num_face_num_verts", C.c_uint),
+                ("shape_face_offset", C.POINTER(C.c_uint)), ("shape_length", C.POINTER(C.c_uint)),
+                ("num_shapes", C.c_uint)]
+
+
+def ref_obj_parse(data: bytes):
+    """One OBJ file through the parser the reference vendors (oracle/_ref/libref_tinyobj.so), or None
+    where it has not been built.  `data` is the file's bytes; the terminating NUL the reference's
+    load_file appends is added here."""
+    global _REF_OBJ
+    if _REF_OBJ is None:
+        path = os.path.join(_HERE, "_ref", "libref_tinyobj.so")
+        if not os.path.exists(path):
+            return None
+        _REF_OBJ = C.CDLL(path)
+        _REF_OBJ.ref_obj_parse.argtypes = [C.POINTER(_RefObj), C.c_char_p, C.c_size_t]
+    buf = data + b"\0"
+    o = _RefObj()
+    rc = _REF_OBJ.ref_obj_parse(C.byref(o), buf, len(buf))
+    if rc != 0:
+        raise RuntimeError(f"reference OBJ parser returned {rc}")
+
+    def arr(ptr, n, dt):
+        return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dt, copy=True) if n else np.zeros(0, dt)
+    return {
+        "vertices": arr(o.vertices, 3 * o.num_vertices, np.float32).reshape(-1, 3),
+        "normals": arr(o.normals, 3 * o.num_normals, np.float32).reshape(-1, 3),
+        "texcoords": arr(o.texcoords, 2 * o.num_texcoords, np.float32).reshape(-1, 2),
+        "faces": arr(o.faces, 3 * o.num_faces, np.int32).reshape(-1, 3),          # {v, vt, vn} per corner
+        "face_num_verts": arr(o.face_num_verts, o.num_face_num_verts, np.int32),
+        "shape_face_offset": arr(o.shape_face_offset, o.num_shapes, np.uint32),
+        "shape_length": arr(o.shape_length, o.num_shapes, np.uint32),
+    }
+
+
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 

@@ -164,6 +164,8 @@ EXPORTED_SYMBOLS = [
     "rt_k_generate_rays", "rt_k_kd_intersect", "rt_k_spath_init", "rt_k_spath_trace", "rt_k_xorshift",
     "rt_k_spath_run", "rt_k_pixel_order", "rt_k_resolve_avg", "rt_k_cast_rays", "rt_k_path_trace", "rt_k_f_buffer_average",
     "rt_k_f_to_byte",
+    # loader.h
+    "load_scene_json", "load_scene_json_url", "load_file", "rt_set_resource_root", "rt_obj_parse", "rt_obj_free",
     # parallel.h
     "cl_info", "create_context", "load_program_raw", "load_program_url", "gen_rgb_image", "gen_grayscale_buffer",
     "gen_1d_image", "gen_1d_image_buffer", "retrieve_buf", "zero_buffer", "zero_buffer_img", "get_workgroup_size",
@@ -240,6 +242,11 @@ def lib():
     L.rt_timing_reset.argtypes = [vp]
     L.rt_timing_get.argtypes = [vp, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
     L.rt_kernel_name.restype = C.c_char_p; L.rt_kernel_name.argtypes = [C.c_int]
+    L.load_scene_json.restype = C.POINTER(scene_t); L.load_scene_json.argtypes = [C.c_char_p]
+    L.load_scene_json_url.restype = C.POINTER(scene_t); L.load_scene_json_url.argtypes = [C.c_char_p]
+    L.rt_set_resource_root.argtypes = [C.c_char_p]
+    L.rt_obj_parse.argtypes = [C.POINTER(rt_obj), C.c_char_p, C.c_size_t]
+    L.rt_obj_free.argtypes = [C.POINTER(rt_obj)]
     L.rt_k_generate_rays.argtypes = [vp, vp, vp, u32, u32, u32, u32, C.c_float]
     L.rt_k_kd_intersect.argtypes = [vp, C.POINTER(rt_kd_view), vp, vp, vp, u32]
     L.rt_k_spath_init.argtypes = [vp, C.POINTER(rt_kd_view), C.POINTER(rt_spath_buffers), u32, u32, u32, u32]
@@ -289,6 +296,66 @@ def lib():
 
 def _vp(a: np.ndarray):
     return a.ctypes.data_as(C.c_void_p)
+
+
+class rt_obj(C.Structure):
+    _fields_ = [("vertices", C.POINTER(C.c_float)), ("num_vertices", C.c_uint),
+                ("normals", C.POINTER(C.c_float)), ("num_normals", C.c_uint),
+                ("texcoords", C.POINTER(C.c_float)), ("num_texcoords", C.c_uint),
+                ("faces", C.POINTER(C.c_int)), ("num_faces", C.c_uint),
+                ("shape_face_offset", C.POINTER(C.c_uint)), ("shape_length", C.POINTER(C.c_uint)),
+                ("num_shapes", C.c_uint), ("num_face_lines", C.c_uint), ("num_nontriangle_lines", C.c_uint)]
+
+
+def obj_parse(data: bytes) -> dict:
+    """One OBJ file through the library's reader (rt_obj_parse); `data` is the file's bytes."""
+    L = lib()
+    buf = data + b"\0"
+    o = rt_obj()
+    rc = L.rt_obj_parse(C.byref(o), buf, len(buf))
+    if rc != 0:
+        raise RuntimeError(f"rt_obj_parse returned {rc}")
+
+    def arr(ptr, n, dt):
+        return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dt, copy=True) if n else np.zeros(0, dt)
+    out = {
+        "vertices": arr(o.vertices, 3 * o.num_vertices, np.float32).reshape(-1, 3),
+        "normals": arr(o.normals, 3 * o.num_normals, np.float32).reshape(-1, 3),
+        "texcoords": arr(o.texcoords, 2 * o.num_texcoords, np.float32).reshape(-1, 2),
+        "faces": arr(o.faces, 3 * o.num_faces, np.int32).reshape(-1, 3),
+        "shape_face_offset": arr(o.shape_face_offset, o.num_shapes, np.uint32),
+        "shape_length": arr(o.shape_length, o.num_shapes, np.uint32),
+        "num_face_lines": int(o.num_face_lines), "num_nontriangle_lines": int(o.num_nontriangle_lines),
+    }
+    L.rt_obj_free(C.byref(o))
+    return out
+
+
+def load_scene(url: str, resource_root: str) -> "scenes.SceneArrays":
+    """A .rsc scene file (and the OBJ meshes it names, both relative to
+    `resource_root`) through load_scene_json_url, copied into SceneArrays."""
+    L = lib()
+    L.rt_set_resource_root(resource_root.encode())
+    sp = L.load_scene_json_url(url.encode())
+    s = sp.contents
+
+    def rec(ptr, n, dt):
+        if not n:
+            return np.zeros(0, dt)
+        raw = C.string_at(ptr, n * np.dtype(dt).itemsize)
+        return np.frombuffer(raw, dt).copy()
+    out = scenes.SceneArrays(
+        verts4=rec(s.mesh_verts, s.num_mesh_verts * 4, np.float32).reshape(-1, 4),
+        normals4=rec(s.mesh_nrmls, s.num_mesh_nrmls * 4, np.float32).reshape(-1, 4),
+        idx4=rec(s.mesh_indices, s.num_mesh_indices * 4, np.int32).reshape(-1, 4),
+        meshes=rec(s.meshes, s.num_meshes, scenes.MESH_DT),
+        materials=rec(s.materials, s.num_materials, scenes.MATERIAL_DT),
+        spheres=rec(s.spheres, s.num_spheres, scenes.SPHERE_DT),
+        planes=rec(s.planes, s.num_planes, scenes.PLANE_DT))
+    out.texcoords = rec(s.mesh_texcoords, s.num_mesh_texcoords * 2, np.float32).reshape(-1, 2)
+    L.scene_free(sp)
+    L.rt_set_resource_root(None)
+    return out
 
 
 def make_scene(sc: "scenes.SceneArrays"):

@@ -244,3 +244,45 @@ def splitmix32(seed: int, index: np.ndarray) -> np.ndarray:
         z = ((z ^ (z >> np.uint64(13))) * np.uint64(0xC2B2AE35)) & np.uint64(0xFFFFFFFF)
         z = z ^ (z >> np.uint64(16))
     return z.astype(np.uint32)
+
+
+def write_rsc(sc: SceneArrays, directory: str, name: str = "scene") -> str:
+    """Writes `sc` as <directory>/<name>.rsc plus one Wavefront OBJ per mesh
+    under <directory>/mesh/ (the file formats of the reference's res/ tree,
+    src/loader.c:228-450) and returns the scene file's name relative to
+    `directory`.  Coordinates are printed with 9 significant digits; the
+    loader's own decimal conversion decides the floats that come back."""
+    import json
+    import os
+    os.makedirs(os.path.join(directory, "mesh"), exist_ok=True)
+    meshes = []
+    for mi, m in enumerate(sc.meshes):
+        first, count = int(m["index_offset"]), int(m["num_indices"])
+        idx = sc.idx4[first:first + count]
+        vs, inv_v = np.unique(idx[:, 0], return_inverse=True)
+        ns, inv_n = np.unique(idx[:, 1], return_inverse=True)
+        lines = [f"o mesh{mi}"]
+        lines += ["v %.9g %.9g %.9g" % tuple(sc.verts4[v, :3]) for v in vs]
+        lines += ["vn %.9g %.9g %.9g" % tuple(sc.normals4[n, :3]) for n in ns]
+        for t in range(count // 3):
+            c = [f"{inv_v[3 * t + j] + 1}//{inv_n[3 * t + j] + 1}" for j in range(3)]
+            lines.append("f " + " ".join(c))
+        url = f"mesh/{name}_{mi}.obj"
+        with open(os.path.join(directory, url), "w") as f:
+            f.write("\n".join(lines) + "\n")
+        meshes.append({"url": url, "mat_index": int(m["material_index"])})
+    desc = {
+        "version": {"major": 0, "minor": 1, "type": "DEV"}, "name": name,
+        "materials": [{"r": float(c[0]), "g": float(c[1]), "b": float(c[2]), "reflectivity": float(r)}
+                      for c, r in zip(sc.materials["colour"], sc.materials["reflectivity"])],
+        "meshes": meshes,
+        "primitives": {
+            "spheres": [{"x": float(s["pos"][0]), "y": float(s["pos"][1]), "z": float(s["pos"][2]),
+                         "radius": float(s["radius"]), "mat_index": int(s["material_index"])} for s in sc.spheres],
+            "planes": [{"x": float(p["pos"][0]), "y": float(p["pos"][1]), "z": float(p["pos"][2]),
+                        "nx": float(p["norm"][0]), "ny": float(p["norm"][1]), "nz": float(p["norm"][2]),
+                        "mat_index": int(p["material_index"])} for p in sc.planes]},
+    }
+    with open(os.path.join(directory, name + ".rsc"), "w") as f:
+        json.dump(desc, f, indent=1)
+    return name + ".rsc"

@@ -150,3 +150,57 @@ def test_deep_stack_scene_bit_exact(rt, orc):
     assert_bits_equal(g["out_tex"], st.out_tex, "out_tex")
     assert_bits_equal(g["rays"], st.rays, "rays")
     assert stats["max_stack"] > 12, stats
+
+
+def test_scene_file_to_pixels(rt, orc, tmp_path):
+    """The whole drop-in chain: .rsc + OBJ files -> load_scene_json_url -> build -> SPATH, against the oracle
+    fed with the arrays the loader produced."""
+    url = rt.scenes.write_rsc(rt.scenes.icosphere_scene(3), str(tmp_path), "ico3")
+    sc = rt.load_scene(url, str(tmp_path))
+    assert sc.num_tris == 20 * 4 ** 3 + 6 and len(sc.meshes) == 4
+    w, h, iters, seed = 80, 48, 7, 4
+    r = rt.Renderer(sc, w, h).build()
+    r.init_spath(seed=seed, resolve_interval=0)
+    r.spath_prepass(num_iterations=iters)
+    r.spath_render(iters)
+    tree = orc.KdTree(sc.verts4, sc.idx4)
+    st = oracle_spath_run(orc, sc, tree, w, h, seed, iters)
+    g = r.spath_state()
+    hits_equal(g["source_results"], st.source_results, "primary hits")
+    hits_equal(g["results"], st.results, "bounce hits")
+    assert_bits_equal(g["out_tex"], st.out_tex, "out_tex")
+    assert_bits_equal(r.spath_resolve(), st.resolve(), "resolved ARGB image")
+    assert (st.source_results["t"] != 0).sum() > 500
+    r.close()
+
+
+def test_headless_front_end(rt, orc, tmp_path):
+    """rt_headless (C, the reference's render-thread call sequence) renders a scene file to a PPM; the pixels are
+    the resolved frame of the same run through the binding."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(rt.LIB_PATH), "rt_headless")
+    assert os.path.exists(exe), "rt_headless is built by raytracer_amd/csrc/Makefile"
+    url = rt.scenes.write_rsc(rt.scenes.icosphere_scene(3), str(tmp_path), "ico3")
+    w, h, samples = 64, 48, 3
+    out = tmp_path / "frame.ppm"
+    env = dict(os.environ, RT_RNG_SEED="9")
+    p = subprocess.run([exe, str(tmp_path), url, str(w), str(h), str(samples), str(out), "spath"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert p.returncode == 0, p.stderr.decode()[-1500:] + p.stdout.decode()[-1500:]
+    raw = out.read_bytes()
+    header = f"P6\n{w} {h}\n255\n".encode()
+    assert raw.startswith(header) and len(raw) == len(header) + 3 * w * h
+    rgb = np.frombuffer(raw[len(header):], np.uint8).reshape(h * w, 3).astype(np.uint32)
+    assert len(np.unique(rgb, axis=0)) > 20          # an image, not a constant
+    # same scene, seed and iteration count through the binding and through the oracle
+    sc = rt.load_scene(url, str(tmp_path))
+    r = rt.Renderer(sc, w, h).build()
+    r.init_spath(seed=9, resolve_interval=50)
+    r.spath_prepass(num_iterations=samples * 4)
+    r.spath_render(samples * 4 + 1)                  # the call after the last iteration resolves the frame
+    frame = r.output.copy()
+    r.close()
+    assert_bits_equal((rgb[:, 0] << 16) | (rgb[:, 1] << 8) | rgb[:, 2], frame & 0xffffff, "PPM pixels")
+    st = oracle_spath_run(orc, sc, orc.KdTree(sc.verts4, sc.idx4), w, h, 9, samples * 4)
+    assert_bits_equal(frame, st.resolve(), "frame against the oracle")
