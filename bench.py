@@ -117,6 +117,7 @@ def main():
     ap.add_argument("--separate-kernels", action="store_true", help="three launches per iteration, as the reference")
     ap.add_argument("--max-batch", type=int, default=None, help="most iterations folded into one launch")
     ap.add_argument("--no-reorder", action="store_true", help="serve pixels in index order in every batch")
+    ap.add_argument("--size", type=int, default=0, help="override the workload's frame: SIZE x SIZE pixels (tuning runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
@@ -152,6 +153,9 @@ def main():
     import raytracer_amd as rt
 
     spec, width, height, desc = WORKLOADS[args.workload]
+    if args.size:
+        width = height = args.size
+        desc += f" [frame overridden: {width}x{height}]"
     if height % world:
         raise SystemExit(f"height {height} is not divisible by {world} ranks")
     strip = height // world

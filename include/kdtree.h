@@ -64,9 +64,9 @@ typedef struct kd_tree_node {
 
 /* flattened tree on the host, uploaded by scene_resource_push (layouts: rt_hip.h) */
 typedef struct kd_tree_flat {
-    uint32_t *nodes;        /* 4 words per interior node */
+    uint32_t *nodes;        /* 8 words per two-level record (layout: rt_hip.h) */
     float    *leaf_tris;    /* 12 floats per slot */
-    uint32_t  num_nodes;    /* interior nodes */
+    uint32_t  num_nodes;    /* records */
     uint32_t  num_leaf_slots;
     uint32_t  root_ref;
 } kd_tree_flat;

@@ -74,12 +74,21 @@ const char *rt_kernel_name(int kernel_id);
 
 /* ---- scene data as the kernels see it ------------------------------------ */
 /* Flattened kd-tree (built by kd_tree_flatten, kdtree.h).
- *   nodes      interior nodes only, 16 bytes each {f32 split, u32 axis, u32 left, u32 right}.
- *              A child reference is an interior node index (bit 31 clear) or a
- *              leaf descriptor (bit 31 set): bits 25..0 = first slot in
+ *   nodes      32-byte records, each an interior node ("top") together with
+ *              its two children where those are interior too:
+ *                word 0..2  f32 split of the top, of its left child, of its right child
+ *                word 3     axis of the top (bits 1..0), of the left child (3..2),
+ *                           of the right child (5..4); bit 6 / bit 7: the left /
+ *                           right child is a leaf
+ *                word 4, 5  references of the left child's children (word 4 =
+ *                           the leaf descriptor when the left child is a leaf)
+ *                word 6, 7  the same for the right child
+ *              A reference is (record index << 2) | position (bit 31 clear;
+ *              position 0 = the record's top, 1 / 2 = its left / right child)
+ *              or a leaf descriptor (bit 31 set): bits 25..0 = first slot in
  *              leaf_tris, bits 30..26 = triangle count, 31 meaning "31 or more,
- *              read the count from the leaf's first slot".  Leaves therefore
- *              cost no node fetch of their own.
+ *              read the count from the leaf's first slot".  One fetch serves
+ *              two descend steps and leaves cost no node fetch of their own.
  *   leaf_tris  48 bytes per slot, leaf order (a triangle referenced by several
  *              leaves is stored once per leaf): {v0.xyz, index offset as u32 bits},
  *              {v1-v0, triangle count of the leaf as u32 bits}, {v2-v0, 0}.
@@ -93,10 +102,10 @@ typedef struct rt_kd_view {
     rt_mem nodes;
     rt_mem leaf_tris;
     rt_mem tri_shade;
-    uint32_t num_nodes;          /* interior nodes */
+    uint32_t num_nodes;          /* records */
     uint32_t num_leaf_slots;
     uint32_t num_tris;
-    uint32_t root_ref;           /* child reference of the root (a leaf descriptor for a one-leaf tree) */
+    uint32_t root_ref;           /* reference of the root (a leaf descriptor for a one-leaf tree) */
     float scene_min[3];      /* SCENE_MIN / SCENE_MAX of src/raytracer.c:53-64 */
     float scene_max[3];
 } rt_kd_view;

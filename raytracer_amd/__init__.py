@@ -388,7 +388,7 @@ class HostKdTree:
         self.bounds_min = np.array(t.bounds.min[:3], np.float32)
         self.bounds_max = np.array(t.bounds.max[:3], np.float32)
         f = t.flat
-        self.nodes = np.ctypeslib.as_array(f.nodes, shape=(max(f.num_nodes, 1), 4)).copy()[:f.num_nodes]
+        self.nodes = np.ctypeslib.as_array(f.nodes, shape=(max(f.num_nodes, 1), 8)).copy()[:f.num_nodes]
         self.leaf_tris = np.ctypeslib.as_array(f.leaf_tris, shape=(max(f.num_leaf_slots, 1), 12)).copy()[:f.num_leaf_slots]
         self.root_ref = int(f.root_ref)
 

@@ -449,34 +449,51 @@ typedef struct flat_ctx {
     uint32_t next_node, next_slot, depth_max;
 } flat_ctx;
 
-/* returns the child reference of n (layout: rt_hip.h) */
+static uint32_t flatten_leaf(flat_ctx *fc, const kd_tree_node *n)
+{
+    const uint32_t cnt = n->triangles.num_triangles;
+    const uint32_t start = fc->next_slot;
+    for (uint32_t i = 0; i < cnt; i++) {
+        const unsigned int off = n->triangles.triangle_buffer[i];
+        const float *a = fc->verts[fc->idx[off][0]];
+        const float *b = fc->verts[fc->idx[off + 1][0]];
+        const float *c = fc->verts[fc->idx[off + 2][0]];
+        float *o = fc->f->leaf_tris + 12 * (size_t)fc->next_slot++;
+        o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; memcpy(&o[3], &off, 4);
+        o[4] = b[0] - a[0]; o[5] = b[1] - a[1]; o[6] = b[2] - a[2]; memcpy(&o[7], &cnt, 4);
+        o[8] = c[0] - a[0]; o[9] = c[1] - a[1]; o[10] = c[2] - a[2]; o[11] = 0.f;
+    }
+    return REF_LEAF | ((cnt < REF_COUNT_MAX ? cnt : REF_COUNT_MAX) << REF_SLOT_BITS) | (cnt ? start : 0u);
+}
+
+/* Returns the reference of n (layout: rt_hip.h).  An interior node becomes the
+   top of a two-level record that also holds its interior children: one fetch
+   serves two descend steps.  Leaves are emitted in depth-first order. */
 static uint32_t flatten_rec(flat_ctx *fc, const kd_tree_node *n, uint32_t depth)
 {
     if (depth > fc->depth_max) fc->depth_max = depth;
-    if (!n->left) {
-        const uint32_t cnt = n->triangles.num_triangles;
-        const uint32_t start = fc->next_slot;
-        for (uint32_t i = 0; i < cnt; i++) {
-            const unsigned int off = n->triangles.triangle_buffer[i];
-            const float *a = fc->verts[fc->idx[off][0]];
-            const float *b = fc->verts[fc->idx[off + 1][0]];
-            const float *c = fc->verts[fc->idx[off + 2][0]];
-            float *o = fc->f->leaf_tris + 12 * (size_t)fc->next_slot++;
-            o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; memcpy(&o[3], &off, 4);
-            o[4] = b[0] - a[0]; o[5] = b[1] - a[1]; o[6] = b[2] - a[2]; memcpy(&o[7], &cnt, 4);
-            o[8] = c[0] - a[0]; o[9] = c[1] - a[1]; o[10] = c[2] - a[2]; o[11] = 0.f;
-        }
-        return REF_LEAF | ((cnt < REF_COUNT_MAX ? cnt : REF_COUNT_MAX) << REF_SLOT_BITS) | (cnt ? start : 0u);
-    }
+    if (!n->left) return flatten_leaf(fc, n);
     const uint32_t self = fc->next_node++;
-    const uint32_t l = flatten_rec(fc, n->left, depth + 1);
-    const uint32_t r = flatten_rec(fc, n->right, depth + 1);
-    uint32_t *w = fc->f->nodes + 4 * (size_t)self;
-    memcpy(&w[0], &n->b, 4);
-    w[1] = (uint32_t)(n->k > 2 ? 2 : n->k);
-    w[2] = l;
-    w[3] = r;
-    return self;
+    uint32_t rec[8] = {0};
+    uint32_t packed = (uint32_t)(n->k > 2 ? 2 : n->k);
+    memcpy(&rec[0], &n->b, 4);
+    const kd_tree_node *child[2] = {n->left, n->right};
+    for (int side = 0; side < 2; side++) {
+        const kd_tree_node *c = child[side];
+        if (depth + 1 > fc->depth_max) fc->depth_max = depth + 1;
+        if (!c->left) {
+            rec[4 + 2 * side] = flatten_leaf(fc, c);
+            packed |= 64u << side;
+        } else {
+            memcpy(&rec[1 + side], &c->b, 4);
+            packed |= (uint32_t)(c->k > 2 ? 2 : c->k) << (2 + 2 * side);
+            rec[4 + 2 * side] = flatten_rec(fc, c->left, depth + 2);
+            rec[5 + 2 * side] = flatten_rec(fc, c->right, depth + 2);
+        }
+    }
+    rec[3] = packed;
+    memcpy(fc->f->nodes + 8 * (size_t)self, rec, sizeof rec);
+    return self << 2;
 }
 
 void kd_tree_flatten(kd_tree *tree)
@@ -486,14 +503,14 @@ void kd_tree_flatten(kd_tree *tree)
     memset(f, 0, sizeof *f);
     if (!tree->root) return;
     /* also keeps both device arrays below 4 GiB: the kernels use 32-bit byte offsets */
-    if (tree->num_traversal_nodes >= (1u << 28) || tree->num_indices_total >= (1u << REF_SLOT_BITS)) {
+    if (tree->num_traversal_nodes >= (1u << 27) || tree->num_indices_total >= (1u << REF_SLOT_BITS)) {
         fprintf(stderr, "ERROR: kd-tree too large for the flattened layout (%u interior nodes, %u leaf slots)\n",
                 tree->num_traversal_nodes, tree->num_indices_total);
         exit(1);
     }
-    f->num_nodes = tree->num_traversal_nodes;
+    /* every record holds at least its top node, so the interior-node count bounds the record count */
     f->num_leaf_slots = tree->num_indices_total;
-    f->nodes = (uint32_t *)malloc(sizeof(uint32_t) * 4 * (size_t)(f->num_nodes ? f->num_nodes : 1));
+    f->nodes = (uint32_t *)malloc(sizeof(uint32_t) * 8 * (size_t)(tree->num_traversal_nodes ? tree->num_traversal_nodes : 1));
     f->leaf_tris = (float *)malloc(sizeof(float) * 12 * (size_t)(f->num_leaf_slots ? f->num_leaf_slots : 1));
     flat_ctx fc;
     fc.f = f;
@@ -501,6 +518,8 @@ void kd_tree_flatten(kd_tree *tree)
     fc.idx = (const int (*)[4])tree->s->mesh_indices;
     fc.next_node = fc.next_slot = fc.depth_max = 0;
     f->root_ref = flatten_rec(&fc, tree->root, 0);
+    f->num_nodes = fc.next_node;
+    f->nodes = (uint32_t *)realloc(f->nodes, sizeof(uint32_t) * 8 * (size_t)(f->num_nodes ? f->num_nodes : 1));
     if (fc.depth_max >= 64) {        /* the traversal stack holds 64 entries */
         fprintf(stderr, "ERROR: kd-tree depth %u exceeds the traversal stack\n", fc.depth_max);
         exit(1);

@@ -201,42 +201,19 @@ __device__ __forceinline__ bool walk_begin(const TravScene &P, Walk &w, f3 o, f3
     return true;
 }
 
-// Fetch what every lane stands on.  Issued by all lanes outside any divergent
-// branch (lanes with nothing to fetch read element 0, one shared cache line)
-// and pinned with an empty asm: left alone, the compiler sinks each load into
-// the branch that uses it and the wave then waits for memory twice per trip.
-// Byte offsets are 32-bit (the host checks both arrays stay below 4 GiB), which
-// keeps the address arithmetic to one shift / one multiply per load.
-__device__ __forceinline__ void walk_fetch(const TravScene &P, const Walk &w, bool walking, uint4 &node, float4 &T0,
-                                           float4 &T1, float4 &T2)
-{
-    const bool at_leaf = (w.ref & RT_REF_LEAF) != 0;
-    const uint32_t nidx = (walking && !at_leaf) ? w.ref : 0u;
-    const uint32_t tslot = (walking && at_leaf && w.li < w.lc) ? w.slot + w.li : 0u;
-    node = *(const uint4 *)((const char *)P.nodes + (nidx << 4));
-    const float4 *tp = (const float4 *)((const char *)P.leaf_tris + tslot * 48u);
-    T0 = tp[0]; T1 = tp[1]; T2 = tp[2];
-    asm volatile("" : "+v"(node.x), "+v"(node.y), "+v"(node.z), "+v"(node.w),
-                      "+v"(T0.x), "+v"(T0.y), "+v"(T0.z), "+v"(T0.w),
-                      "+v"(T1.x), "+v"(T1.y), "+v"(T1.z), "+v"(T1.w),
-                      "+v"(T2.x), "+v"(T2.y), "+v"(T2.z));
-}
-
-// One descend step of a lane standing on an interior node,
-// reference: src/kernels/kdtree.cl:229-260.  get_elem (:67-75) adds the
-// masked-out zeros, which turns -0 into +0.
+// One descend step at an interior node with split plane (k, b) and children
+// (left, right), reference: src/kernels/kdtree.cl:229-260.  get_elem (:67-75)
+// adds the masked-out zeros, which turns -0 into +0.
 template <int LDS_DEPTH>
-__device__ __forceinline__ void walk_interior(Walk &w, f3 o, f3 d, const uint4 &node, uint2 *__restrict__ col,
-                                              uint2 *__restrict__ spill)
+__device__ __forceinline__ void walk_descend(Walk &w, f3 o, f3 d, uint32_t k, float b, uint32_t left, uint32_t right,
+                                             uint2 *__restrict__ col, uint2 *__restrict__ spill)
 {
-    const uint32_t k = node.y;
-    const float b = __uint_as_float(node.x);
     const float ok = ((k == 0) ? o.x : ((k == 1) ? o.y : o.z)) + 0.0f;
     const float dk = ((k == 0) ? d.x : ((k == 1) ? d.y : d.z)) + 0.0f;
     const float t_split = (b - ok) / dk;
     const bool left_close = (ok < b) || (ok == b && dk <= 0);
-    const uint32_t first = left_close ? node.z : node.w;
-    const uint32_t second = left_close ? node.w : node.z;
+    const uint32_t first = left_close ? left : right;
+    const uint32_t second = left_close ? right : left;
     const bool c1 = (t_split > w.t_max || t_split <= 0);
     const bool c2 = (t_split < w.t_min);
     if (!c1 && !c2) {
@@ -247,6 +224,32 @@ __device__ __forceinline__ void walk_interior(Walk &w, f3 o, f3 d, const uint4 &
         w.t_max = t_split;
     }
     walk_enter(w, (c1 || !c2) ? first : second);
+}
+
+// The lane stands on an interior node: fetch its two-level record (32 bytes,
+// layout in rt_hip.h) and descend -- from the record's top through one of its
+// children when that child is interior too, so up to two levels per fetch; a
+// lane that arrives at a child position (popped from the stack) takes one.
+template <int LDS_DEPTH>
+__device__ __forceinline__ void walk_interior(const TravScene &P, Walk &w, f3 o, f3 d, uint2 *__restrict__ col,
+                                              uint2 *__restrict__ spill)
+{
+    const uint32_t top = w.ref & ~3u;                    // reference of the record's top = record index * 4
+    const uint4 *rec = (const uint4 *)((const char *)P.nodes + (top << 3));
+    uint4 a = rec[0], r = rec[1];
+    // both halves are fetched here, together: left alone, the compiler sinks the
+    // words only the first step needs into that branch, as a second round trip
+    asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(r.x), "+v"(r.y), "+v"(r.z), "+v"(r.w));
+    const uint32_t packed = a.w;
+    if ((w.ref & 3u) == 0u) {
+        const uint32_t left = (packed & 64u) ? r.x : (top | 1u);
+        const uint32_t right = (packed & 128u) ? r.z : (top | 2u);
+        walk_descend<LDS_DEPTH>(w, o, d, packed & 3u, __uint_as_float(a.x), left, right, col, spill);
+        if ((w.ref & RT_REF_LEAF) || (w.ref & 3u) == 0u) return;     // at a leaf (cannot be another record's top here)
+    }
+    const bool at_left = (w.ref & 3u) == 1u;
+    walk_descend<LDS_DEPTH>(w, o, d, (packed >> (at_left ? 2 : 4)) & 3u, __uint_as_float(at_left ? a.y : a.z),
+                            at_left ? r.x : r.z, at_left ? r.y : r.w, col, spill);
 }
 
 // One step of a lane standing in a leaf (src/kernels/kdtree.cl:263-302): test
@@ -307,24 +310,6 @@ __device__ __forceinline__ bool walk_leaf_load(const TravScene &P, Walk &w, f3 o
         T0 = tp[0]; T1 = tp[1]; T2 = tp[2];
     }
     return walk_leaf<LDS_DEPTH>(P, w, o, d, T0, T1, T2, col, spill);
-}
-
-// One step of a walking lane, whichever kind of node it stands on.
-template <int LDS_DEPTH>
-__device__ __forceinline__ bool walk_step(const TravScene &P, Walk &w, f3 o, f3 d, const uint4 &node,
-                                          const float4 &T0, const float4 &T1, const float4 &T2,
-                                          uint2 *__restrict__ col, uint2 *__restrict__ spill)
-{
-    if (!(w.ref & RT_REF_LEAF)) { walk_interior<LDS_DEPTH>(w, o, d, node, col, spill); return false; }
-    return walk_leaf<LDS_DEPTH>(P, w, o, d, T0, T1, T2, col, spill);
-}
-
-// Single-kind fetches for the slots of a trip that serve only one kind of lane;
-// called by those lanes only (the loads are exec-masked, idle lanes cost the
-// cache nothing).
-__device__ __forceinline__ uint4 walk_load_node(const TravScene &P, const Walk &w)
-{
-    return *(const uint4 *)((const char *)P.nodes + (w.ref << 4));
 }
 
 __device__ __forceinline__ Hit walk_result(const Walk &w)
@@ -407,11 +392,14 @@ __global__ __launch_bounds__(64) void k_kd_intersect(TravScene P, const float4 *
             if (q.exhausted) break;
             continue;
         }
-        uint4 node; float4 T0, T1, T2;
-        walk_fetch(P, w, walking, node, T0, T1, T2);
-        if (walking && walk_step<LDS_DEPTH>(P, w, o, d, node, T0, T1, T2, col, spill)) {
-            hits[ridx] = walk_result(w);
-            walking = false;
+        // one record (up to two descend steps) for the lanes on interior nodes,
+        // then one triangle for the lanes in leaves
+        if (walking && !(w.ref & RT_REF_LEAF)) walk_interior<LDS_DEPTH>(P, w, o, d, col, spill);
+        if (walking && (w.ref & RT_REF_LEAF)) {
+            if (walk_leaf_load<LDS_DEPTH>(P, w, o, d, col, spill)) {
+                hits[ridx] = walk_result(w);
+                walking = false;
+            }
         }
     }
 }
@@ -450,21 +438,22 @@ __device__ __forceinline__ void spath_step(const float4 *__restrict__ tri_shade,
     float rand1 = get_random(seed1, seed2);
     float rand2 = get_random(seed2, seed1);
 
-    f3 sdir = cosine_hemisphere(rand1, rand2, sf.normal);
-    f3 sorig = pos + sf.normal * 0.0001f;
-
+    // The reference samples a bounce direction at the hit, updates mask with it,
+    // and, when this bounce ends the sample (a miss or the fourth bounce),
+    // resets mask and samples again at the primary hit with the same two random
+    // numbers (path.cl:176-250).  In that case nothing of the first direction
+    // survives, so the hemisphere sample is evaluated once, at whichever surface
+    // the next ray leaves from.
+    const bool finish = (res.t == 0) || (bounce_num + 1 >= 4);
     if (res.t == 0) {
-        bounce_num = 4;
         accum = accum + mask * sky;
     } else {
         float e = (sf.refl == 1.f) ? 1.0f : 0.0f;
         accum = accum + (mask * e) * 2.f;
-        mask = mask * sf.colour;
-        mask = mask * dot3(sdir, sf.normal);
     }
-    bounce_num++;
 
-    if (bounce_num >= 4) {
+    Surface from = sf;
+    if (finish) {
         bounce_num = 0;
         sample_num++;
         float4 ot = out_tex[i];
@@ -477,12 +466,17 @@ __device__ __forceinline__ void spath_step(const float4 *__restrict__ tri_shade,
         if (res.t == 0) { ot.x += sky.x; ot.y += sky.y; ot.z += sky.z; ot.w += 0.0f; }
         out_tex[i] = ot;
 
-        sf = surface_at(tri_shade, res);
+        from = surface_at(tri_shade, res);
         pos = o + d * res.t;
+        mask = mask * from.colour;
+        if (from.refl == 1.f) accum = accum + mask * 2.f;
+    }
+    const f3 sdir = cosine_hemisphere(rand1, rand2, from.normal);
+    const f3 sorig = pos + from.normal * 0.0001f;
+    if (!finish) {
         mask = mask * sf.colour;
-        if (sf.refl == 1.f) accum = accum + mask * 2.f;
-        sdir = cosine_hemisphere(rand1, rand2, sf.normal);
-        sorig = pos + sf.normal * 0.0001f;
+        mask = mask * dot3(sdir, sf.normal);
+        bounce_num++;
     }
     new_o = sorig; new_d = sdir;
     pa = mk4(mask, __uint_as_float(sample_num));
@@ -601,11 +595,11 @@ __global__ void k_spath_trace(const float4 *__restrict__ tri_shade, float4 *__re
 // ended wait until SHADE_MIN of them can be served together (or nothing else is
 // left to do); the same service pass hands pixels to free lanes.
 //
-// Walk slots of a trip: NI descend slots, then NT leaf slots.  In each slot only
-// the lanes standing on that kind of node load and step (exec-masked, so idle
-// lanes cost the cache nothing); a lane that reaches its leaf in a descend slot
-// tests its first triangle in the same trip.  NI == 0 selects the older shape:
-// one step per lane per trip, node and triangle fetched together.
+// Walk slots of a trip: NI descend slots (one two-level record each), then NT
+// leaf slots (one triangle each).  In each slot only the lanes standing on that
+// kind of node load and step (exec-masked, so idle lanes cost the cache
+// nothing); a lane that reaches its leaf in a descend slot tests its first
+// triangle in the same trip.
 //
 // WAVES is the occupancy the register allocation is held to (waves per SIMD):
 // waves spend more than half of their time waiting for gathers, so a seventh
@@ -692,33 +686,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
             if (q.exhausted && !__any(mode == DONE)) break;
             continue;
         }
-        if (NI == 0) {
-            // one step per lane per trip, both kinds of node fetched together
-            uint4 node; float4 T0, T1, T2;
-            walk_fetch(P, w, mode == WALK, node, T0, T1, T2);
-            if (mode == WALK) {
+        // up to NI records (two descend steps each), then up to NT triangles: a
+        // lane that reaches its leaf within the trip tests its triangles in the
+        // same trip
+#pragma unroll
+        for (int r = 0; r < NI; r++) {
+            if (mode == WALK && !(w.ref & RT_REF_LEAF)) {
                 steps++;
-                if (walk_step<LDS_DEPTH>(P, w, o, d, node, T0, T1, T2, col, spill)) mode = DONE;
+                walk_interior<LDS_DEPTH>(P, w, o, d, col, spill);
             }
-        } else {
-            // up to NI descend steps, then up to NT leaf steps: a lane that reaches
-            // its leaf within the trip tests its triangles in the same trip
+        }
 #pragma unroll
-            for (int r = 0; r < NI; r++) {
-                const bool interior = mode == WALK && !(w.ref & RT_REF_LEAF);
-                if (interior) {
-                    const uint4 node = walk_load_node(P, w);
-                    steps++;
-                    walk_interior<LDS_DEPTH>(w, o, d, node, col, spill);
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < NT; r++) {
-                const bool leaf = mode == WALK && (w.ref & RT_REF_LEAF);
-                if (leaf) {
-                    steps++;
-                    if (walk_leaf_load<LDS_DEPTH>(P, w, o, d, col, spill)) mode = DONE;
-                }
+        for (int r = 0; r < NT; r++) {
+            if (mode == WALK && (w.ref & RT_REF_LEAF)) {
+                steps++;
+                if (walk_leaf_load<LDS_DEPTH>(P, w, o, d, col, spill)) mode = DONE;
             }
         }
     }
@@ -1159,16 +1141,14 @@ void launch_spath_run(rt_device *dev, const TravScene &P, const SpathDev &B, uin
         variant = e ? atoi(e) : 0;
     }
     switch (variant) {
-    case 1: launch_run_variant<12, 16, 64, 2, 1, 6>(dev, P, B, n, iters, rv); break;
-    case 2: launch_run_variant<12, 16, 0, 2, 1, 6>(dev, P, B, n, iters, rv); break;
-    case 3: launch_run_variant<10, 16, 0, 2, 1, 7>(dev, P, B, n, iters, rv); break;
-    case 4: launch_run_variant<10, 16, 64, 2, 1, 7>(dev, P, B, n, iters, rv); break;
-    case 5: launch_run_variant<10, 24, 64, 2, 1, 7>(dev, P, B, n, iters, rv); break;
-    case 6: launch_run_variant<10, 16, 64, 3, 1, 7>(dev, P, B, n, iters, rv); break;
-    case 7: launch_run_variant<10, 16, 64, 1, 1, 7>(dev, P, B, n, iters, rv); break;
-    case 8: launch_run_variant<12, 16, 64, 3, 2, 5>(dev, P, B, n, iters, rv); break;
-    case 9: launch_run_variant<10, 8, 64, 2, 1, 7>(dev, P, B, n, iters, rv); break;
-    default: launch_run_variant<10, 16, 64, 2, 1, 7>(dev, P, B, n, iters, rv); break;
+    case 1: launch_run_variant<10, 16, 64, 2, 1, 7>(dev, P, B, n, iters, rv); break;
+    case 2: launch_run_variant<12, 16, 64, 1, 1, 6>(dev, P, B, n, iters, rv); break;
+    case 3: launch_run_variant<12, 16, 64, 2, 1, 6>(dev, P, B, n, iters, rv); break;
+    case 4: launch_run_variant<10, 16, 64, 2, 2, 7>(dev, P, B, n, iters, rv); break;
+    case 5: launch_run_variant<10, 16, 64, 1, 2, 7>(dev, P, B, n, iters, rv); break;
+    case 6: launch_run_variant<12, 16, 64, 2, 1, 5>(dev, P, B, n, iters, rv); break;
+    case 7: launch_run_variant<12, 16, 64, 1, 1, 5>(dev, P, B, n, iters, rv); break;
+    default: launch_run_variant<10, 16, 64, 1, 1, 7>(dev, P, B, n, iters, rv); break;
     }
 }
 

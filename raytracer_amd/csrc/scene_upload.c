@@ -111,7 +111,7 @@ void scene_resource_push(raytracer_context *rctx)
     int first_push = (kdt->cl_kd_tree_buffer == NULL);
     if (first_push && kdt->root) {
         kd_tree_flatten(kdt);
-        kdt->cl_kd_tree_buffer = upload_array(rctx, kdt->flat.nodes, sizeof(uint32_t) * 4 * (size_t)kdt->flat.num_nodes);
+        kdt->cl_kd_tree_buffer = upload_array(rctx, kdt->flat.nodes, sizeof(uint32_t) * 8 * (size_t)kdt->flat.num_nodes);
         kdt->view.nodes = kdt->cl_kd_tree_buffer;
         /* the kernels may read slot 0 / node 0 as a harmless dummy: keep both allocated */
         kdt->view.leaf_tris = rt_mem_alloc(dev, sizeof(float) * 12 * ((size_t)kdt->flat.num_leaf_slots + 1));

@@ -74,8 +74,8 @@ def test_product_builder_matches_oracle(rt, orc, name, threads):
 
 
 def _decode_flat(hk):
-    """Leaves of the flattened tree in depth-first order: list of index-offset tuples."""
-    leaves = []
+    """Depth-first walk of the flattened tree: (leaves as index-offset tuples, interior nodes as (axis, split bits))."""
+    leaves, interior = [], []
 
     def walk(ref):
         if ref & 0x80000000:
@@ -84,20 +84,29 @@ def _decode_flat(hk):
                 cnt = int(hk.leaf_tris[slot, 7].view(np.uint32))
             leaves.append(tuple(int(hk.leaf_tris[slot + i, 3].view(np.uint32)) for i in range(cnt)))
             return
-        n = hk.nodes[ref]
-        walk(int(n[2]))
-        walk(int(n[3]))
+        rec, pos = hk.nodes[ref >> 2], ref & 3
+        packed = int(rec[3])
+        interior.append(((packed >> (2 * pos)) & 3, int(rec[pos])))
+        if pos == 0:       # top of a record: its children are positions 1 / 2 of the same record, or leaves
+            walk(int(rec[4]) if packed & 64 else (ref | 1))
+            walk(int(rec[6]) if packed & 128 else (ref | 2))
+        else:
+            assert not packed & (32 << pos)
+            walk(int(rec[2 + 2 * pos]))
+            walk(int(rec[3 + 2 * pos]))
     import sys
     sys.setrecursionlimit(10000)
     walk(hk.root_ref)
-    return leaves
+    return leaves, interior
 
 
 def _decode_blob(blob):
-    leaves, off = [], 0
+    """The same from the reference's wire format, which is in depth-first order already."""
+    leaves, interior, off = [], [], 0
     while off < blob.shape[0]:
         t = int(blob[off])
         if t == 2:
+            interior.append((int(blob[off + 1]), int(blob[off + 4:off + 8].view(np.uint32)[0])))
             off += 32
         elif t == 1:
             n = int(blob[off + 4:off + 8].view(np.uint32)[0])
@@ -105,7 +114,7 @@ def _decode_blob(blob):
             off += 16 + 4 * n + (4 if n % 2 else 0)
         else:
             break
-    return leaves
+    return leaves, interior
 
 
 @pytest.mark.parametrize("name", ["ico4", "soup2k"])
@@ -113,7 +122,11 @@ def test_flattened_tree_has_the_same_leaves_in_the_same_order(rt, orc, name):
     sc = _scenes(rt)[name]
     hk = rt.HostKdTree(sc)
     kt = orc.KdTree(sc.verts4, sc.idx4)
-    assert _decode_flat(hk) == _decode_blob(kt.blob[:kt.blob_used])
+    flat_leaves, flat_interior = _decode_flat(hk)
+    blob_leaves, blob_interior = _decode_blob(kt.blob[:kt.blob_used])
+    assert flat_leaves == blob_leaves
+    assert flat_interior == blob_interior and len(flat_interior) == hk.counts["traversal"]
+    assert hk.nodes.shape[0] < hk.counts["traversal"]          # two levels per record
     # precomputed edges are exactly v1-v0, v2-v0
     off = int(hk.leaf_tris[0, 3].view(np.uint32))
     a, b, c = (sc.verts4[sc.idx4[off + i, 0], :3] for i in range(3))
