@@ -8,10 +8,10 @@ pixel's path = one ray per pixel traced through the kd-tree and shaded.  The
 default workload is the million-triangle configuration the headline metric is
 quoted on: a 1,310,720-triangle displaced icosphere in a room with an emissive
 quad ("c3"), 2048x2048 pixels.  With N > 1 (one process per GPU, launched by
-torch.distributed.run) the frame is split into N row strips, each rank renders
-its strip with the scene replicated, and the resolved strips are gathered to
-rank 0 over RCCL at the end of the timed region; total work is fixed, so the
-scaling is strong.
+torch.distributed.run) the frame's rows are dealt to the ranks in bands of 8,
+each rank renders its rows with the scene replicated, and the resolved rows are
+gathered to rank 0 over RCCL at the end of the timed region; total work is
+fixed, so the scaling is strong.
 
 Rank 0 prints ONE JSON line: Mrays/s of the whole job, the HBM roofline figure
 of the dominant kernel (algorithmic bytes per launch / measured launch time)
@@ -156,15 +156,19 @@ def main():
     if args.size:
         width = height = args.size
         desc += f" [frame overridden: {width}x{height}]"
-    if height % world:
-        raise SystemExit(f"height {height} is not divisible by {world} ranks")
-    strip = height // world
-    y0 = rank * strip
+    # Interleaved bands of rows: every rank gets rows from all over the frame, so the expensive centre of the
+    # picture is shared out evenly (contiguous strips of this scene differ by 2x in cost).
+    from raytracer_amd.strips import BAND_ROWS, band_partition
+    try:
+        first, band, stride, strip = band_partition(height, world, rank)
+    except ValueError as e:
+        raise SystemExit(str(e))
 
     t0 = time.perf_counter()
     sc = make_scene(spec)
     t_scene = time.perf_counter() - t0
-    r = rt.Renderer(sc, width, strip, device=local_rank, tile_y0=y0, full_height=height)
+    r = rt.Renderer(sc, width, strip, device=local_rank, tile_y0=first, full_height=height,
+                    bands=(band, stride) if world > 1 else None)
     t0 = time.perf_counter()
     r.build()
     t_build = time.perf_counter() - t0
@@ -173,7 +177,7 @@ def main():
     r.spath_prepass(num_iterations=1 << 30)
     if rank == 0:
         log(f"[bench] {desc}: {sc.num_tris} triangles, scene {t_scene:.1f}s, build {t_build:.1f}s, "
-            f"{r.kdt.num_nodes_total} nodes, strip {width}x{strip} per rank, device {r.device_props()['name']}")
+            f"{r.kdt.num_nodes_total} nodes, {width}x{strip} pixels per rank, device {r.device_props()['name']}")
 
     def sync_all():
         r.sync()
@@ -222,7 +226,11 @@ def main():
     # its checksum goes into the line so runs at different N can be compared.
     import zlib
     if torch is not None:
-        frame_crc = zlib.crc32(torch.cat(gathered).cpu().numpy().tobytes()) if rank == 0 else 0
+        if rank == 0:       # bands back into frame order: [rank, band of the rank, pixels] -> [band, rank, pixels]
+            whole = torch.stack(gathered).view(world, strip // band, band * width).transpose(0, 1).reshape(-1)
+            frame_crc = zlib.crc32(whole.cpu().numpy().tobytes())
+        else:
+            frame_crc = 0
     else:
         frame_crc = zlib.crc32(r.spath_resolve().tobytes())
 
@@ -251,7 +259,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {desc}", "triangles": int(sc.num_tris), "width": width,
                        "height": height, "rows_per_gpu": strip, "kernel": kname, "frame_crc32": f"{frame_crc:08x}",
-                       "partition": f"{world} row strips + RCCL gather of the resolved frame" if world > 1 else "single GPU"},
+                       "partition": f"{BAND_ROWS}-row bands dealt to {world} ranks + RCCL gather of the resolved frame" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": kname, "avg_launch_ms": round(avg_ms, 4), "launches": launches,

@@ -59,6 +59,8 @@ struct _rt_ctx {
     rt_mem cl_ray_dir_buffer;        /* ray directions, float4 per pixel */
     unsigned int tile_y0;            /* this context renders rows [tile_y0, tile_y0+height) ... */
     unsigned int full_height;        /* ... of a frame full_height rows high (0 = height) */
+    unsigned int tile_band;          /* != 0: the rows come in bands of tile_band rows, tile_stride frame rows apart */
+    unsigned int tile_stride;
 };
 
 raytracer_context *raytracer_init(unsigned int width, unsigned int height,
@@ -75,6 +77,12 @@ void _raytracer_cast_rays(raytracer_context *rctx);
 
 /* not in the reference: multi-GPU row strips.  Call before raytracer_build. */
 void raytracer_set_tile(raytracer_context *rctx, unsigned int y0, unsigned int full_height);
+/* Interleaved partition: local row j is frame row first + (j / band) * stride + (j % band).  With `world` ranks,
+   band rows each, rank r uses first = r * band, stride = world * band: every rank gets rows from all over the frame. */
+void raytracer_set_tile_bands(raytracer_context *rctx, unsigned int first, unsigned int band, unsigned int stride,
+                              unsigned int full_height);
+/* The row mapping of this context as the kernels take it. */
+void raytracer_get_rows(const raytracer_context *rctx, rt_rows *rows);
 void raytracer_destroy(raytracer_context *rctx);
 
 #endif

@@ -138,10 +138,20 @@ typedef struct rt_spath_buffers {
 } rt_spath_buffers;
 
 /* ---- kernel launches ------------------------------------------------------ */
+/* Which rows of the full frame a context renders (multi-GPU partitions; no
+   counterpart in the reference, which renders whole frames).  Local row j is
+   frame row  first + (j / band) * stride + (j % band);  band == 0 means one
+   contiguous strip, first + j.  Pixel coordinates that enter the arithmetic
+   (camera rays, RNG seeds) are always those of the full frame. */
+typedef struct rt_rows {
+    uint32_t first, band, stride;
+    uint32_t full_height;
+} rt_rows;
+
 /* generate_rays (src/kernels/ray.cl:109-133; host src/raytracer.c:182-206).
-   Rows [y0, y0+h) of a frame full_h high; tan_half_fov is tanf(40 deg). */
+   h local rows mapped into the full frame by `rows`; tan_half_fov is tanf(40 deg). */
 void rt_k_generate_rays(rt_device *dev, rt_mem ray_o, rt_mem ray_d, uint32_t w, uint32_t h,
-                        uint32_t y0, uint32_t full_h, float tan_half_fov);
+                        const rt_rows *rows, float tan_half_fov);
 
 /* kdtree_intersection (src/kernels/kdtree.cl:90-321; host src/spath_raytracer.c:136-171).
    Persistent waves pull rays from a device-side work counter (the reference
@@ -152,7 +162,7 @@ void rt_k_kd_intersect(rt_device *dev, const rt_kd_view *kd, rt_mem ray_o, rt_me
 
 /* segmented_path_trace_init (src/kernels/path.cl:36-113; host src/spath_raytracer.c:280-316). */
 void rt_k_spath_init(rt_device *dev, const rt_kd_view *kd, const rt_spath_buffers *b, uint32_t w, uint32_t h,
-                     uint32_t y0, uint32_t random_value);
+                     const rt_rows *rows, uint32_t random_value);
 
 /* segmented_path_trace (src/kernels/path.cl:115-258; host src/spath_raytracer.c:318-353).
    With step_rng != 0 the per-pixel RNG word is advanced first (xorshift_batch

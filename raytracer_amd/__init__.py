@@ -105,7 +105,12 @@ class raytracer_context(C.Structure):
                 ("cl_ray_buffer", C.c_void_p), ("cl_output_buffer", C.c_void_p),
                 ("path_output_buffer", C.c_void_p), ("num_samples", C.c_uint), ("current_sample", C.c_uint),
                 ("cl_path_output_buffer", C.c_void_p), ("cl_path_fresh_frame_buffer", C.c_void_p),
-                ("cl_ray_dir_buffer", C.c_void_p), ("tile_y0", C.c_uint), ("full_height", C.c_uint)]
+                ("cl_ray_dir_buffer", C.c_void_p), ("tile_y0", C.c_uint), ("full_height", C.c_uint),
+                ("tile_band", C.c_uint), ("tile_stride", C.c_uint)]
+
+
+class rt_rows(C.Structure):
+    _fields_ = [("first", C.c_uint32), ("band", C.c_uint32), ("stride", C.c_uint32), ("full_height", C.c_uint32)]
 
 
 class ss_raytracer_context(C.Structure):
@@ -147,7 +152,7 @@ _ABI_STRUCTS = {"rcl_ctx": rcl_ctx, "rcl_program": rcl_program, "rcl_img_buf": r
                 "AABB": AABB, "rt_device_props": rt_device_props}
 _ABI_OFFSETS = [("raytracer_context", "stat_scene"), ("raytracer_context", "rcl"),
                 ("raytracer_context", "cl_ray_buffer"), ("raytracer_context", "cl_ray_dir_buffer"),
-                ("raytracer_context", "tile_y0"), ("raytracer_context", "num_samples"),
+                ("raytracer_context", "tile_y0"), ("raytracer_context", "tile_stride"), ("raytracer_context", "num_samples"),
                 ("scene", "kdt"), ("scene", "mesh_indices"), ("scene", "num_mesh_indices"),
                 ("kd_tree", "bounds"), ("kd_tree", "buffer"), ("kd_tree", "flat"), ("kd_tree", "view"),
                 ("kd_tree", "build_threads"), ("spath_raytracer_context", "cl_random_buffer"),
@@ -182,7 +187,7 @@ EXPORTED_SYMBOLS = [
     # raytracer.h
     "raytracer_init", "raytracer_build", "raytracer_prepass", "raytracer_render", "raytracer_refined_render",
     "_raytracer_gen_ray_buffer", "_raytracer_path_trace", "_raytracer_average_buffers", "_raytracer_push_path",
-    "_raytracer_cast_rays", "raytracer_set_tile", "raytracer_destroy",
+    "_raytracer_cast_rays", "raytracer_set_tile", "raytracer_set_tile_bands", "raytracer_get_rows", "raytracer_destroy",
     # ss_raytracer.h / path_raytracer.h / spath_raytracer.h
     "init_ss_raytracer_context", "ss_raytracer_render", "ss_raytracer_prepass",
     "init_path_raytracer_context", "path_raytracer_render", "path_raytracer_prepass",
@@ -247,9 +252,9 @@ def lib():
     L.rt_set_resource_root.argtypes = [C.c_char_p]
     L.rt_obj_parse.argtypes = [C.POINTER(rt_obj), C.c_char_p, C.c_size_t]
     L.rt_obj_free.argtypes = [C.POINTER(rt_obj)]
-    L.rt_k_generate_rays.argtypes = [vp, vp, vp, u32, u32, u32, u32, C.c_float]
+    L.rt_k_generate_rays.argtypes = [vp, vp, vp, u32, u32, C.POINTER(rt_rows), C.c_float]
     L.rt_k_kd_intersect.argtypes = [vp, C.POINTER(rt_kd_view), vp, vp, vp, u32]
-    L.rt_k_spath_init.argtypes = [vp, C.POINTER(rt_kd_view), C.POINTER(rt_spath_buffers), u32, u32, u32, u32]
+    L.rt_k_spath_init.argtypes = [vp, C.POINTER(rt_kd_view), C.POINTER(rt_spath_buffers), u32, u32, C.POINTER(rt_rows), u32]
     L.rt_k_spath_trace.argtypes = [vp, C.POINTER(rt_kd_view), C.POINTER(rt_spath_buffers), u32, u32, C.c_int]
     L.rt_k_xorshift.argtypes = [vp, vp, u32]
     L.rt_k_spath_run.argtypes = [vp, C.POINTER(rt_kd_view), C.POINTER(rt_spath_buffers), u32, u32, vp, vp, vp]
@@ -274,6 +279,8 @@ def lib():
     L._raytracer_path_trace.argtypes = [C.POINTER(raytracer_context), C.c_uint]
     L._raytracer_average_buffers.argtypes = [C.POINTER(raytracer_context), C.c_uint]
     L.raytracer_set_tile.argtypes = [C.POINTER(raytracer_context), C.c_uint, C.c_uint]
+    L.raytracer_set_tile_bands.argtypes = [C.POINTER(raytracer_context), C.c_uint, C.c_uint, C.c_uint, C.c_uint]
+    L.raytracer_get_rows.argtypes = [C.POINTER(raytracer_context), C.POINTER(rt_rows)]
     L.init_ss_raytracer_context.restype = C.POINTER(ss_raytracer_context)
     L.init_ss_raytracer_context.argtypes = [C.POINTER(raytracer_context)]
     L.ss_raytracer_render.argtypes = [C.POINTER(ss_raytracer_context)]
@@ -408,7 +415,10 @@ class Renderer:
     X_render."""
 
     def __init__(self, sc: "scenes.SceneArrays", width: int, height: int, device: int | None = None,
-                 tile_y0: int = 0, full_height: int | None = None, build_threads: int = 0):
+                 tile_y0: int = 0, full_height: int | None = None, build_threads: int = 0,
+                 bands: tuple[int, int] | None = None):
+        """`height` local rows.  full_height given: they are rows tile_y0.. of a frame that high (a contiguous
+        strip), or, with bands=(band, stride), the interleaved rows tile_y0 + (j // band) * stride + j % band."""
         L = lib()
         self.L = L
         self.sc = sc
@@ -422,7 +432,9 @@ class Renderer:
         self.rctx = L.raytracer_init(width, height, self.output.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(self.rcl))
         self.scene = make_scene(sc)
         self.rctx.contents.stat_scene = self.scene
-        if full_height is not None:
+        if full_height is not None and bands is not None:
+            L.raytracer_set_tile_bands(self.rctx, tile_y0, bands[0], bands[1], full_height)
+        elif full_height is not None:
             L.raytracer_set_tile(self.rctx, tile_y0, full_height)
         self._build_threads = build_threads
         self.spath = None

@@ -25,7 +25,7 @@ size_t rt_abi_query(const char *name)
     SIZE_OF(_skd_tree_traversal_node); SIZE_OF(_skd_tree_leaf_node);
     OFFSET_OF(raytracer_context, stat_scene); OFFSET_OF(raytracer_context, rcl);
     OFFSET_OF(raytracer_context, cl_ray_buffer); OFFSET_OF(raytracer_context, cl_ray_dir_buffer);
-    OFFSET_OF(raytracer_context, tile_y0); OFFSET_OF(raytracer_context, num_samples);
+    OFFSET_OF(raytracer_context, tile_y0); OFFSET_OF(raytracer_context, tile_stride); OFFSET_OF(raytracer_context, num_samples);
     OFFSET_OF(scene, kdt); OFFSET_OF(scene, mesh_indices); OFFSET_OF(scene, num_mesh_indices);
     OFFSET_OF(kd_tree, bounds); OFFSET_OF(kd_tree, buffer); OFFSET_OF(kd_tree, flat); OFFSET_OF(kd_tree, view);
     OFFSET_OF(kd_tree, build_threads);

@@ -36,6 +36,24 @@ void raytracer_set_tile(raytracer_context *rctx, unsigned int y0, unsigned int f
 {
     rctx->tile_y0 = y0;
     rctx->full_height = full_height;
+    rctx->tile_band = rctx->tile_stride = 0;
+}
+
+void raytracer_set_tile_bands(raytracer_context *rctx, unsigned int first, unsigned int band, unsigned int stride,
+                              unsigned int full_height)
+{
+    rctx->tile_y0 = first;
+    rctx->full_height = full_height;
+    rctx->tile_band = band;
+    rctx->tile_stride = stride;
+}
+
+void raytracer_get_rows(const raytracer_context *rctx, rt_rows *rows)
+{
+    rows->first = rctx->tile_y0;
+    rows->band = rctx->tile_band;
+    rows->stride = rctx->tile_stride;
+    rows->full_height = rctx->full_height ? rctx->full_height : rctx->height;
 }
 
 /* reference: src/raytracer.c:81-126 (no kernels are compiled here: they ship prebuilt) */
@@ -73,9 +91,10 @@ void raytracer_prepass(raytracer_context *rctx)
 void _raytracer_gen_ray_buffer(raytracer_context *rctx)
 {
     const float tan_half = tanf(RT_FOV_DEG / 2 * RT_PI_F / 180);
-    const unsigned int full_h = rctx->full_height ? rctx->full_height : rctx->height;
+    rt_rows rows;
+    raytracer_get_rows(rctx, &rows);
     rt_k_generate_rays(rctx->rcl->device, rctx->cl_ray_buffer, rctx->cl_ray_dir_buffer, rctx->width, rctx->height,
-                       rctx->tile_y0, full_h, tan_half);
+                       &rows, tan_half);
     rt_device_sync(rctx->rcl->device);
 }
 

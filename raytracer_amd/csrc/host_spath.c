@@ -91,8 +91,15 @@ static void upload_random_buffer(spath_raytracer_context *c)
     raytracer_context *rctx = c->rctx;
     const size_t n = (size_t)rctx->width * rctx->height;
     if (c->rng_mode == RT_RNG_SPLITMIX) {
-        const size_t first = (size_t)rctx->tile_y0 * rctx->width;
-        for (size_t i = 0; i < n; i++) c->random_buffer[i] = splitmix32(c->rng_seed, (uint32_t)(first + i));
+        /* the word of a pixel depends on its position in the full frame only */
+        rt_rows rows;
+        raytracer_get_rows(rctx, &rows);
+        for (unsigned int j = 0; j < rctx->height; j++) {
+            const size_t row = rows.band ? rows.first + (size_t)(j / rows.band) * rows.stride + j % rows.band
+                                         : (size_t)rows.first + j;
+            for (unsigned int x = 0; x < rctx->width; x++)
+                c->random_buffer[(size_t)j * rctx->width + x] = splitmix32(c->rng_seed, (uint32_t)(row * rctx->width + x));
+        }
     } else {
         for (size_t i = 0; i < n; i++) c->random_buffer[i] = (unsigned int)rand();
     }
@@ -174,7 +181,9 @@ void spath_raytracer_prepass(spath_raytracer_context *c)
     rt_spath_buffers b;
     spath_raytracer_fill_buffers(c, &b);
     rt_k_kd_intersect(dev, &kdt->view, b.ray_o, b.ray_d, b.hits, n);
-    rt_k_spath_init(dev, &kdt->view, &b, rctx->width, rctx->height, rctx->tile_y0, next_random_value(c));
+    rt_rows rows;
+    raytracer_get_rows(rctx, &rows);
+    rt_k_spath_init(dev, &kdt->view, &b, rctx->width, rctx->height, &rows, next_random_value(c));
     upload_random_buffer(c);
 
     /* the reference clears the ray buffer here (src/spath_raytracer.c:432-433),

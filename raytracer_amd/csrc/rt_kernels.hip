@@ -488,12 +488,19 @@ __device__ __forceinline__ void spath_step(const float4 *__restrict__ tri_shade,
 // ---------------------------------------------------------------------------
 // generate_rays, reference: src/kernels/ray.cl:109-133.  The reference's 0.5
 // literals are doubles, so the camera-plane coordinates go through double.
+__device__ __forceinline__ uint32_t frame_row(const rt_rows &rows, uint32_t local_row)
+{
+    return rows.band ? rows.first + (local_row / rows.band) * rows.stride + (local_row % rows.band)
+                     : rows.first + local_row;
+}
+
 __global__ void k_generate_rays(float4 *__restrict__ ray_o, float4 *__restrict__ ray_d, uint32_t w, uint32_t h,
-                                uint32_t y0, uint32_t full_h, float tan_half)
+                                rt_rows rows, float tan_half)
 {
     uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= w * h) return;
-    uint32_t x = id % w, y = id / w + y0;
+    uint32_t x = id % w, y = frame_row(rows, id / w);
+    const uint32_t full_h = rows.full_height;
     float aspect = w / (float)full_h;
     float cam_x = (float)((2 * (((float)x + 0.5) / w) - 1) * tan_half * aspect);
     float cam_y = (float)((1 - 2 * (((float)y + 0.5) / full_h)) * tan_half);
@@ -510,11 +517,11 @@ __global__ void k_spath_init(const float4 *__restrict__ tri_shade, float4 *__res
                              float4 *__restrict__ origin_o, float4 *__restrict__ origin_d,
                              const Hit *__restrict__ hits, Hit *__restrict__ source_hits,
                              float4 *__restrict__ prog_a, float4 *__restrict__ prog_b, uint32_t w, uint32_t h,
-                             uint32_t y0, uint32_t random_value)
+                             rt_rows rows, uint32_t random_value)
 {
     uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= w * h) return;
-    uint32_t x = id % w, y = id / w + y0;
+    uint32_t x = id % w, y = frame_row(rows, id / w);
 
     Hit res = hits[id];
     float4 ro = ray_o[id], rd = ray_d[id];
@@ -1158,14 +1165,32 @@ void launch_spath_run(rt_device *dev, const TravScene &P, const SpathDev &B, uin
 
 extern "C" {
 
-void rt_k_generate_rays(rt_device *dev, rt_mem ray_o, rt_mem ray_d, uint32_t w, uint32_t h, uint32_t y0,
-                        uint32_t full_h, float tan_half_fov)
+// The kernels index frame rows without bounds of their own: refuse a mapping
+// that leaves the frame.
+static void check_rows(const rt_rows *rows, uint32_t h, const char *who)
+{
+    bool ok = rows && rows->full_height > 0;
+    if (ok && h) {
+        const uint32_t last = h - 1;
+        const uint64_t row = rows->band ? (uint64_t)rows->first + (uint64_t)(last / rows->band) * rows->stride + last % rows->band
+                                        : (uint64_t)rows->first + last;
+        ok = row < rows->full_height && (!rows->band || rows->stride >= rows->band);
+    }
+    if (!ok) {
+        fprintf(stderr, "ERROR: %s: the row mapping leaves the frame\n", who);
+        exit(1);
+    }
+}
+
+void rt_k_generate_rays(rt_device *dev, rt_mem ray_o, rt_mem ray_d, uint32_t w, uint32_t h, const rt_rows *rows,
+                        float tan_half_fov)
 {
     uint32_t n = w * h;
     if (!n) return;
+    check_rows(rows, h, "rt_k_generate_rays");
     rt_launch_timer tm(dev, RT_K_GENERATE_RAYS);
     hipLaunchKernelGGL(k_generate_rays, dim3(blocks_for(n, 256)), dim3(256), 0, dev->stream, (float4 *)ray_o,
-                       (float4 *)ray_d, w, h, y0, full_h, tan_half_fov);
+                       (float4 *)ray_d, w, h, *rows, tan_half_fov);
     RT_AFTER_LAUNCH();
 }
 
@@ -1183,15 +1208,16 @@ void rt_k_kd_intersect(rt_device *dev, const rt_kd_view *kd, rt_mem ray_o, rt_me
 }
 
 void rt_k_spath_init(rt_device *dev, const rt_kd_view *kd, const rt_spath_buffers *b, uint32_t w, uint32_t h,
-                     uint32_t y0, uint32_t random_value)
+                     const rt_rows *rows, uint32_t random_value)
 {
     if (!(w * h)) return;
     check_kd(kd, "rt_k_spath_init");
+    check_rows(rows, h, "rt_k_spath_init");
     rt_launch_timer tm(dev, RT_K_SPATH_INIT);
     hipLaunchKernelGGL(k_spath_init, dim3(blocks_for(w * h, 256)), dim3(256), 0, dev->stream,
                        (const float4 *)kd->tri_shade, (float4 *)b->out_tex, (float4 *)b->ray_o, (float4 *)b->ray_d,
                        (float4 *)b->origin_o, (float4 *)b->origin_d, (const Hit *)b->hits, (Hit *)b->source_hits,
-                       (float4 *)b->prog_a, (float4 *)b->prog_b, w, h, y0, random_value);
+                       (float4 *)b->prog_a, (float4 *)b->prog_b, w, h, *rows, random_value);
     RT_AFTER_LAUNCH();
 }
 

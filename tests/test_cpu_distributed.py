@@ -53,3 +53,32 @@ def test_two_rank_strips_equal_single_frame(tmp_path, orc, rt, h):
     tree = orc.KdTree(sc.verts4, sc.idx4)
     want = oracle_spath_run(orc, sc, tree, w, h, seed, iters).resolve()
     assert np.array_equal(got, want)
+
+
+def _band_worker(rank, world, port, w, h, out_path):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from raytracer_amd.strips import band_rows, gather_bands
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    rows = band_rows(h, world, rank)
+    # every pixel carries its own frame coordinates
+    local = torch.tensor([[y * w + x for x in range(w)] for y in rows], dtype=torch.int32).reshape(-1)
+    frame = gather_bands(local, w, h, dist, rank, world)
+    if rank == 0:
+        np.save(out_path, frame.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_band_gather_restores_frame_order(tmp_path):
+    import torch.multiprocessing as mp
+    from raytracer_amd.strips import band_partition, band_rows
+    w, h, world = 5, 48, 2
+    out = str(tmp_path / "bands.npy")
+    mp.spawn(_band_worker, args=(world, _free_port(), w, h, out), nprocs=world, join=True)
+    assert np.array_equal(np.load(out), np.arange(w * h, dtype=np.int32))
+    assert band_partition(48, 2, 1) == (8, 8, 16, 24)
+    assert band_rows(32, 2, 1)[:9] == [8, 9, 10, 11, 12, 13, 14, 15, 24]
+    with pytest.raises(ValueError):
+        band_partition(50, 2, 0)

@@ -76,7 +76,8 @@ def test_first_bounce_rays_bit_exact(rt, orc, small):
     r.L.rt_k_kd_intersect(r.dev, C.byref(kd), b.ray_o, b.ray_d, b.hits, n)
     from raytracer_amd.scenes import splitmix32
     rv = int(splitmix32(seed + 1, np.arange(1, dtype=np.uint64))[0])
-    r.L.rt_k_spath_init(r.dev, C.byref(kd), C.byref(b), w, h, 0, rv)
+    rows = rt.rt_rows(0, 0, 0, h)
+    r.L.rt_k_spath_init(r.dev, C.byref(kd), C.byref(b), w, h, C.byref(rows), rv)
     r.sync()
     g = r.spath_state()
     st = orc.SpathState(sc, tree, w, h)
@@ -105,6 +106,35 @@ def test_tile_equals_full_frame(rt, orc, small):
     assert_bits_equal(got, ref[y0:y0 + th], "strip vs full frame")
     st = oracle_spath_run(orc, sc, tree, w, th, seed, iters, y0=y0, full_h=h)
     assert_bits_equal(got.reshape(-1, 4), st.out_tex, "strip vs oracle strip")
+
+
+def test_interleaved_bands_equal_full_frame(rt, orc, small):
+    """Rows dealt to 3 ranks in bands of 8: each rank's pixels are the full frame's pixels of those rows."""
+    from raytracer_amd.strips import band_partition, band_rows
+    sc, tree = small
+    w, h, iters, seed, world = 64, 48, 6, 7, 3
+    full = rt.Renderer(sc, w, h).build()
+    full.init_spath(seed=seed, resolve_interval=0)
+    full.spath_prepass(iters)
+    full.spath_render(iters)
+    ref = full.spath_state()["out_tex"].reshape(h, w, 4)
+    ref_img = full.spath_resolve().reshape(h, w)
+    full.close()
+    seen = []
+    for rank in range(world):
+        first, band, stride, rows = band_partition(h, world, rank)
+        part = rt.Renderer(sc, w, rows, tile_y0=first, full_height=h, bands=(band, stride)).build()
+        part.init_spath(seed=seed, resolve_interval=0)
+        part.spath_prepass(iters)
+        part.spath_render(iters)
+        got = part.spath_state()["out_tex"].reshape(rows, w, 4)
+        img = part.spath_resolve().reshape(rows, w)
+        part.close()
+        where = band_rows(h, world, rank)
+        seen += where
+        assert_bits_equal(got, ref[where], f"rank {rank} out_tex")
+        assert_bits_equal(img, ref_img[where], f"rank {rank} image")
+    assert sorted(seen) == list(range(h))
 
 
 def test_batches_and_heaviest_first_order_do_not_change_results(rt, orc, small):
