@@ -6,10 +6,10 @@ from raytracer_amd.strips import band_partition
 BANDS = len(sys.argv) > 1 and sys.argv[1] == 'bands'
 sc = rt.scenes.icosphere_scene(8)
 W = H = 2048
-for N in (2, 4, 8):
+for N in ((8,) if len(sys.argv) > 2 else (2, 4, 8)):
     rows = H // N
     ts = []
-    for k in range(N):
+    for k in range(N if len(sys.argv) <= 2 else 2):
         if BANDS:
             first, band, stride, rows = band_partition(H, N, k)
             r = rt.Renderer(sc, W, rows, tile_y0=first, full_height=H, bands=(band, stride)).build()

@@ -234,3 +234,81 @@ def test_headless_front_end(rt, orc, tmp_path):
     assert_bits_equal((rgb[:, 0] << 16) | (rgb[:, 1] << 8) | rgb[:, 2], frame & 0xffffff, "PPM pixels")
     st = oracle_spath_run(orc, sc, orc.KdTree(sc.verts4, sc.idx4), w, h, 9, samples * 4)
     assert_bits_equal(frame, st.resolve(), "frame against the oracle")
+
+
+@pytest.mark.parametrize("size", [(1, 1), (33, 17), (65, 3), (7, 130)])
+def test_odd_frame_sizes(rt, orc, small, size):
+    """Frames that fill no wave, a fraction of one, or end in a ragged one."""
+    sc, tree = small
+    w, h = size
+    iters, seed = 6, 21
+    r = rt.Renderer(sc, w, h).build()
+    r.init_spath(seed=seed, resolve_interval=0)
+    r.spath_prepass(num_iterations=iters)
+    r.spath_render(iters)
+    st = oracle_spath_run(orc, sc, tree, w, h, seed, iters)
+    g = r.spath_state()
+    hits_equal(g["source_results"], st.source_results, "primary hits")
+    hits_equal(g["results"], st.results, "bounce hits")
+    assert_bits_equal(g["rays"], st.rays, "rays")
+    assert_bits_equal(g["progress"], st.progress, "progress")
+    assert_bits_equal(g["out_tex"], st.out_tex, "out_tex")
+    assert_bits_equal(r.spath_resolve(), st.resolve(), "image")
+    r.close()
+
+
+def test_single_leaf_tree(rt, orc):
+    """Two triangles: the builder refuses to split, the root is a leaf.  The reference walks such a tree as if the
+    root were an interior node (undefined); here and in the oracle the leaf is tested once."""
+    S = rt.scenes
+    sc = S._assemble([S._quad((-2, -2, -5), (2, -2, -6), (2, 2, -5), (-2, 2, -6), (0, 0, 1)) + (3,)],
+                     S._materials(S._PATH_MATERIALS))
+    tree = orc.KdTree(sc.verts4, sc.idx4)
+    w, h, iters, seed = 40, 24, 5, 2
+    r = rt.Renderer(sc, w, h).build()
+    r.init_spath(seed=seed, resolve_interval=0)
+    r.spath_prepass(num_iterations=iters)
+    assert r.kdt.view.root_ref & 0x80000000
+    r.spath_render(iters)
+    st = oracle_spath_run(orc, sc, tree, w, h, seed, iters)
+    g = r.spath_state()
+    hits_equal(g["source_results"], st.source_results, "primary hits")
+    assert 0 < (st.source_results["t"] != 0).sum() < w * h
+    hits_equal(g["results"], st.results, "bounce hits")
+    assert_bits_equal(g["out_tex"], st.out_tex, "out_tex")
+    r.close()
+
+
+def test_kd_intersect_arbitrary_rays(rt, orc, small):
+    """rt_k_kd_intersect on rays no camera produces: origins inside and far outside the scene box, directions with
+    exact zeros, negative zeros, denormal and huge components, all-zero rays; a count that fills no whole wave."""
+    import ctypes as C
+    sc, tree = small
+    rng = np.random.RandomState(5)
+    n = 10007
+    o = rng.uniform(-12, 12, size=(n, 3)).astype(np.float32)
+    o[: n // 3] = rng.uniform(-40, 40, size=(n // 3, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    special = np.array([0.0, -0.0, 1e-42, -1e-42, 1e30, -1e30, 1.0, -1.0], np.float32)
+    for k in range(0, 3000):                 # sprinkle special values into single components
+        d[k, rng.randint(3)] = special[rng.randint(len(special))]
+    d[3000:3010] = 0.0
+    o[3010:3020] = 0.0
+    rays = np.zeros((n, 8), np.float32)
+    rays[:, 0:3], rays[:, 4:7] = o, d
+    r = rt.Renderer(sc, 8, 8).build()
+    r.L.raytracer_prepass(r.rctx)            # uploads the flattened tree
+    ro = r.L.rt_mem_alloc(r.dev, 16 * n); rd = r.L.rt_mem_alloc(r.dev, 16 * n); hits = r.L.rt_mem_alloc(r.dev, 16 * n)
+    r.upload(ro, np.ascontiguousarray(rays[:, 0:4])); r.upload(rd, np.ascontiguousarray(rays[:, 4:8]))
+    r.L.rt_k_kd_intersect(r.dev, C.byref(r.kdt.view), ro, rd, hits, n)
+    r.sync()
+    got = r.download(hits, np.uint32, 4 * n).reshape(n, 4)
+    want = tree.intersect(rays)
+    assert_bits_equal(got[:, 0], want["tri"], "index offset")
+    for k, f in ((1, "t"), (2, "u"), (3, "v")):
+        assert_bits_equal(got[:, k], want[f].view(np.uint32), f)
+    assert 0.05 < (want["t"] != 0).mean() < 0.95
+    for m in (ro, rd, hits):
+        r.L.rt_mem_free(r.dev, m)
+    r.close()
