@@ -117,6 +117,8 @@ def main():
     ap.add_argument("--separate-kernels", action="store_true", help="three launches per iteration, as the reference")
     ap.add_argument("--max-batch", type=int, default=None, help="most iterations folded into one launch")
     ap.add_argument("--no-reorder", action="store_true", help="serve pixels in index order in every batch")
+    ap.add_argument("--schedule", type=int, default=None, choices=[0, 1],
+                    help="fix the kernel's slot schedule (default: the library times both on its first batch)")
     ap.add_argument("--size", type=int, default=0, help="override the workload's frame: SIZE x SIZE pixels (tuning runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
@@ -173,7 +175,7 @@ def main():
     r.build()
     t_build = time.perf_counter() - t0
     r.init_spath(seed=1, separate_kernels=args.separate_kernels, resolve_interval=50, quiet=True,
-                 max_batch=args.max_batch, reorder=not args.no_reorder)
+                 max_batch=args.max_batch, reorder=not args.no_reorder, schedule=args.schedule)
     r.spath_prepass(num_iterations=1 << 30)
     if rank == 0:
         log(f"[bench] {desc}: {sc.num_tris} triangles, scene {t_scene:.1f}s, build {t_build:.1f}s, "
@@ -258,7 +260,8 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {desc}", "triangles": int(sc.num_tris), "width": width,
-                       "height": height, "rows_per_gpu": strip, "kernel": kname, "frame_crc32": f"{frame_crc:08x}",
+                       "height": height, "rows_per_gpu": strip, "kernel": kname,
+                       "schedule": int(r.spath.contents.schedule), "frame_crc32": f"{frame_crc:08x}",
                        "partition": f"{BAND_ROWS}-row bands dealt to {world} ranks + RCCL gather of the resolved frame" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

@@ -72,6 +72,16 @@ void rt_timing_reset(rt_device *dev);
 void rt_timing_get(rt_device *dev, int kernel_id, uint64_t *launches, double *total_ms);
 const char *rt_kernel_name(int kernel_id);
 
+/* Stream markers for callers that time a stretch of queued work themselves
+   (clEnqueueMarker / clGetEventProfilingInfo in OpenCL terms).  rt_event_record
+   queues a marker on the current stream; rt_event_elapsed_ms waits for `stop`
+   and returns the device time between the two; both are released with
+   rt_event_release. */
+typedef void *rt_event;
+rt_event rt_event_record(rt_device *dev);
+float    rt_event_elapsed_ms(rt_device *dev, rt_event start, rt_event stop);
+void     rt_event_release(rt_device *dev, rt_event e);
+
 /* ---- scene data as the kernels see it ------------------------------------ */
 /* Flattened kd-tree (built by kd_tree_flatten, kdtree.h).
  *   nodes      32-byte records, each an interior node ("top") together with
@@ -180,9 +190,13 @@ void rt_k_xorshift(rt_device *dev, rt_mem random, uint32_t n);
    Buffers end up exactly as iters rounds of the three separate launches leave them.
    cost (n words, required) receives the number of walk steps each pixel took;
    order (n words, or NULL for 0,1,2,...) is the sequence in which pixels are
-   handed to lanes -- scheduling only, results do not depend on it. */
+   handed to lanes -- scheduling only, results do not depend on it.  schedule
+   picks how many triangle slots follow the descend slot in each trip of the
+   kernel's loop (RT_SCHEDULE_*): also scheduling only. */
+#define RT_SCHEDULE_ONE_LEAF_SLOT  0   /* scenes whose rays test about as many triangles as they fetch node records */
+#define RT_SCHEDULE_TWO_LEAF_SLOTS 1   /* triangle-heavy walks (unstructured soups, long leaves) */
 void rt_k_spath_run(rt_device *dev, const rt_kd_view *kd, const rt_spath_buffers *b, uint32_t n, uint32_t iters,
-                    rt_mem random_values, rt_mem cost, rt_mem order);
+                    rt_mem random_values, rt_mem cost, rt_mem order, int schedule);
 
 /* Pixel indices sorted by decreasing cost >> shift (counting sort, 256 buckets)
    into order[0..n); hist256 is 256 words of scratch.  Pixels of equal bucket

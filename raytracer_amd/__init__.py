@@ -136,7 +136,9 @@ class spath_raytracer_context(C.Structure):
                 ("quiet", C.c_bool), ("max_batch", C.c_uint), ("pending", C.c_uint),
                 ("pending_values", C.POINTER(C.c_uint)), ("cl_random_value_buffer", C.c_void_p),
                 ("cl_pixel_cost_buffer", C.c_void_p), ("cl_pixel_order_buffer", C.c_void_p),
-                ("cl_cost_hist_buffer", C.c_void_p), ("order_valid", C.c_bool), ("no_reorder", C.c_int)]
+                ("cl_cost_hist_buffer", C.c_void_p), ("order_valid", C.c_bool), ("no_reorder", C.c_int),
+                ("schedule", C.c_int), ("schedule_fixed", C.c_int), ("trial_state", C.c_int),
+                ("trial_marks", C.c_void_p * 3), ("trial_iters", C.c_uint * 2)]
 
 
 class rt_device_props(C.Structure):
@@ -165,7 +167,7 @@ EXPORTED_SYMBOLS = [
     # rt_hip.h
     "rt_device_count", "rt_device_open", "rt_device_close", "rt_device_get_props", "rt_device_sync",
     "rt_device_stream", "rt_device_ordinal", "rt_device_select_stream", "rt_mem_alloc", "rt_mem_free", "rt_mem_upload", "rt_mem_download",
-    "rt_mem_zero", "rt_mem_copy", "rt_timing_enable", "rt_timing_reset", "rt_timing_get", "rt_kernel_name",
+    "rt_mem_zero", "rt_mem_copy", "rt_event_record", "rt_event_elapsed_ms", "rt_event_release", "rt_timing_enable", "rt_timing_reset", "rt_timing_get", "rt_kernel_name",
     "rt_k_generate_rays", "rt_k_kd_intersect", "rt_k_spath_init", "rt_k_spath_trace", "rt_k_xorshift",
     "rt_k_spath_run", "rt_k_pixel_order", "rt_k_resolve_avg", "rt_k_cast_rays", "rt_k_path_trace", "rt_k_f_buffer_average",
     "rt_k_f_to_byte",
@@ -257,7 +259,7 @@ def lib():
     L.rt_k_spath_init.argtypes = [vp, C.POINTER(rt_kd_view), C.POINTER(rt_spath_buffers), u32, u32, C.POINTER(rt_rows), u32]
     L.rt_k_spath_trace.argtypes = [vp, C.POINTER(rt_kd_view), C.POINTER(rt_spath_buffers), u32, u32, C.c_int]
     L.rt_k_xorshift.argtypes = [vp, vp, u32]
-    L.rt_k_spath_run.argtypes = [vp, C.POINTER(rt_kd_view), C.POINTER(rt_spath_buffers), u32, u32, vp, vp, vp]
+    L.rt_k_spath_run.argtypes = [vp, C.POINTER(rt_kd_view), C.POINTER(rt_spath_buffers), u32, u32, vp, vp, vp, C.c_int]
     L.rt_k_pixel_order.argtypes = [vp, vp, vp, vp, u32, u32, u32]
     L.rt_k_resolve_avg.argtypes = [vp, vp, vp, u32]
     L.rt_k_f_buffer_average.argtypes = [vp, vp, vp, u32, u32]
@@ -453,7 +455,7 @@ class Renderer:
         return self.scene.contents.kdt.contents
 
     def init_spath(self, seed: int = 1, separate_kernels: bool = False, resolve_interval: int = 50, quiet: bool = True,
-                   max_batch: int | None = None, reorder: bool = True):
+                   max_batch: int | None = None, reorder: bool = True, schedule: int | None = None):
         if not self.built:
             self.build()
         self.spath = self.L.init_spath_raytracer_context(self.rctx)
@@ -466,6 +468,9 @@ class Renderer:
         if max_batch is not None:
             c.max_batch = max_batch
         c.no_reorder = 0 if reorder else 1
+        if schedule is not None:         # None: the library tries both on its first long batch
+            c.schedule = schedule
+            c.schedule_fixed = 1
         return self.spath
 
     def spath_prepass(self, num_iterations: int | None = None):

@@ -106,7 +106,22 @@ static void upload_random_buffer(spath_raytracer_context *c)
     rt_mem_upload(rctx->rcl->device, c->cl_random_buffer, c->random_buffer, n * sizeof(unsigned int));
 }
 
-/* f_buffer_to_byte_buffer_avg + blocking readback, reference: src/spath_raytracer.c:252-277 */
+/* Reads the two timings of a queued schedule trial (waits for the launches) and keeps the faster schedule; the
+   second one has to win by 5 % to displace the default. */
+static void finish_schedule_trial(spath_raytracer_context *c)
+{
+    if (c->trial_state != 1) return;
+    rt_device *dev = c->rctx->rcl->device;
+    const float a = rt_event_elapsed_ms(dev, c->trial_marks[0], c->trial_marks[1]) / (float)c->trial_iters[0];
+    const float b = rt_event_elapsed_ms(dev, c->trial_marks[1], c->trial_marks[2]) / (float)c->trial_iters[1];
+    c->schedule = (b < 0.95f * a) ? RT_SCHEDULE_TWO_LEAF_SLOTS : RT_SCHEDULE_ONE_LEAF_SLOT;
+    for (int k = 0; k < 3; k++) { rt_event_release(dev, c->trial_marks[k]); c->trial_marks[k] = NULL; }
+    c->trial_state = 2;
+    if (!c->quiet)
+        printf("schedule trial: %.3f / %.3f ms per iteration -> %s\n", a, b,
+               c->schedule == RT_SCHEDULE_TWO_LEAF_SLOTS ? "two leaf slots" : "one leaf slot");
+}
+
 /* Launches the iterations recorded since the last flush as one batch. */
 void spath_raytracer_flush(spath_raytracer_context *c)
 {
@@ -126,8 +141,26 @@ void spath_raytracer_flush(spath_raytracer_context *c)
                          rctx->width);
         c->order_valid = true;
     }
-    rt_k_spath_run(dev, &rctx->stat_scene->kdt->view, &b, n, c->pending, c->cl_random_value_buffer,
-                   c->cl_pixel_cost_buffer, (c->order_valid && !c->no_reorder) ? c->cl_pixel_order_buffer : NULL);
+    finish_schedule_trial(c);
+    const rt_mem order = (c->order_valid && !c->no_reorder) ? c->cl_pixel_order_buffer : NULL;
+    if (!c->schedule_fixed && c->trial_state == 0 && c->pending >= 16 && n >= 65536) {
+        /* the two halves of this batch run under one schedule each, back to back, in the same pixel order */
+        const unsigned int half = c->pending / 2;
+        c->trial_iters[0] = half;
+        c->trial_iters[1] = c->pending - half;
+        c->trial_marks[0] = rt_event_record(dev);
+        rt_k_spath_run(dev, &rctx->stat_scene->kdt->view, &b, n, half, c->cl_random_value_buffer,
+                       c->cl_pixel_cost_buffer, order, RT_SCHEDULE_ONE_LEAF_SLOT);
+        c->trial_marks[1] = rt_event_record(dev);
+        rt_k_spath_run(dev, &rctx->stat_scene->kdt->view, &b, n, c->pending - half,
+                       (char *)c->cl_random_value_buffer + sizeof(unsigned int) * half,
+                       c->cl_pixel_cost_buffer, order, RT_SCHEDULE_TWO_LEAF_SLOTS);
+        c->trial_marks[2] = rt_event_record(dev);
+        c->trial_state = 1;
+    } else {
+        rt_k_spath_run(dev, &rctx->stat_scene->kdt->view, &b, n, c->pending, c->cl_random_value_buffer,
+                       c->cl_pixel_cost_buffer, order, c->schedule);
+    }
     if (!c->no_reorder && n >= 65536) {
         /* the next batch serves the pixels that were heaviest in this one first;
            bucket width ~ 1/64 of a typical pixel's cost (about 32 steps per iteration) */
@@ -157,6 +190,7 @@ void spath_raytracer_prepass(spath_raytracer_context *c)
     const unsigned int n = rctx->width * rctx->height;
     const size_t n16 = (size_t)n * sizeof(vec4);
 
+    finish_schedule_trial(c);        /* a decision taken for this scene is kept across renders */
     c->render_complete = false;
     c->num_iterations = 2048 * 4;
     c->rng_launch = 0;
@@ -241,6 +275,7 @@ void spath_raytracer_destroy(spath_raytracer_context *c)
 {
     if (!c) return;
     rt_device *dev = c->rctx->rcl->device;
+    finish_schedule_trial(c);
     rt_mem_free(dev, c->cl_path_output_buffer);
     rt_mem_free(dev, c->cl_path_ray_origin_buffer);
     rt_mem_free(dev, c->cl_path_ray_origin_dir_buffer);

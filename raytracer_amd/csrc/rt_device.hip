@@ -152,6 +152,29 @@ void rt_timing_get(rt_device *dev, int kernel_id, uint64_t *launches, double *to
     *total_ms = dev->slots[kernel_id].total_ms;
 }
 
+rt_event rt_event_record(rt_device *dev)
+{
+    hipEvent_t e;
+    RT_HIP_CHECK(hipEventCreate(&e));
+    RT_HIP_CHECK(hipEventRecord(e, dev->stream));
+    return (rt_event)e;
+}
+
+float rt_event_elapsed_ms(rt_device *dev, rt_event start, rt_event stop)
+{
+    (void)dev;
+    float ms = 0.f;
+    RT_HIP_CHECK(hipEventSynchronize((hipEvent_t)stop));
+    RT_HIP_CHECK(hipEventElapsedTime(&ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return ms;
+}
+
+void rt_event_release(rt_device *dev, rt_event e)
+{
+    (void)dev;
+    if (e) RT_HIP_CHECK(hipEventDestroy((hipEvent_t)e));
+}
+
 const char *rt_kernel_name(int kernel_id)
 {
     return (kernel_id >= 0 && kernel_id < RT_K_COUNT) ? k_kernel_names[kernel_id] : "?";

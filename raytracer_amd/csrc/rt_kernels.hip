@@ -1140,12 +1140,19 @@ void launch_run_variant(rt_device *dev, const TravScene &P, const SpathDev &B, u
     RT_HIP_CHECK(hipGetLastError());
 }
 
-void launch_spath_run(rt_device *dev, const TravScene &P, const SpathDev &B, uint32_t n, uint32_t iters, const uint32_t *rv)
+void launch_spath_run(rt_device *dev, const TravScene &P, const SpathDev &B, uint32_t n, uint32_t iters, const uint32_t *rv,
+                      int schedule)
 {
+    // RT_RUN_VARIANT (environment, read once) overrides the schedule with one of the
+    // compiled parameter sets, for tuning runs
     static int variant = -1;
     if (variant < 0) {
         const char *e = getenv("RT_RUN_VARIANT");
         variant = e ? atoi(e) : 0;
+    }
+    if (variant == 0 && schedule == RT_SCHEDULE_TWO_LEAF_SLOTS) {
+        launch_run_variant<12, 16, 64, 1, 2, 5>(dev, P, B, n, iters, rv);
+        return;
     }
     switch (variant) {
     case 1: launch_run_variant<10, 16, 64, 2, 1, 7>(dev, P, B, n, iters, rv); break;
@@ -1155,6 +1162,9 @@ void launch_spath_run(rt_device *dev, const TravScene &P, const SpathDev &B, uin
     case 5: launch_run_variant<10, 16, 64, 1, 2, 7>(dev, P, B, n, iters, rv); break;
     case 6: launch_run_variant<12, 16, 64, 2, 1, 5>(dev, P, B, n, iters, rv); break;
     case 7: launch_run_variant<12, 16, 64, 1, 1, 5>(dev, P, B, n, iters, rv); break;
+    case 8: launch_run_variant<12, 16, 64, 1, 2, 6>(dev, P, B, n, iters, rv); break;
+    case 9: launch_run_variant<12, 16, 64, 1, 2, 5>(dev, P, B, n, iters, rv); break;   // = RT_SCHEDULE_TWO_LEAF_SLOTS
+    case 10: launch_run_variant<12, 16, 64, 2, 2, 5>(dev, P, B, n, iters, rv); break;
     default: launch_run_variant<10, 16, 64, 1, 1, 7>(dev, P, B, n, iters, rv); break;
     }
 }
@@ -1261,7 +1271,7 @@ void rt_k_pixel_order(rt_device *dev, rt_mem cost, rt_mem order, rt_mem hist256,
 }
 
 void rt_k_spath_run(rt_device *dev, const rt_kd_view *kd, const rt_spath_buffers *b, uint32_t n, uint32_t iters,
-                    rt_mem random_values, rt_mem cost, rt_mem order)
+                    rt_mem random_values, rt_mem cost, rt_mem order, int schedule)
 {
     if (!n || !iters) return;
     check_kd(kd, "rt_k_spath_run");
@@ -1280,7 +1290,7 @@ void rt_k_spath_run(rt_device *dev, const rt_kd_view *kd, const rt_spath_buffers
     B.cost = (uint32_t *)cost;
     B.order = (const uint32_t *)order;
     if (!cost) { fprintf(stderr, "ERROR: rt_k_spath_run needs a per-pixel cost buffer\n"); exit(1); }
-    launch_spath_run(dev, P, B, n, iters, (const uint32_t *)random_values);
+    launch_spath_run(dev, P, B, n, iters, (const uint32_t *)random_values, schedule);
 }
 
 void rt_k_resolve_avg(rt_device *dev, rt_mem out_u32, rt_mem out_tex, uint32_t n)
