@@ -1156,12 +1156,12 @@ void launch_spath_run(rt_device *dev, const TravScene &P, const SpathDev &B, uin
     }
     switch (variant) {
     case 1: launch_run_variant<10, 16, 64, 2, 1, 7>(dev, P, B, n, iters, rv); break;
-    case 2: launch_run_variant<12, 16, 64, 1, 1, 6>(dev, P, B, n, iters, rv); break;
-    case 3: launch_run_variant<12, 16, 64, 2, 1, 6>(dev, P, B, n, iters, rv); break;
-    case 4: launch_run_variant<10, 16, 64, 2, 2, 7>(dev, P, B, n, iters, rv); break;
-    case 5: launch_run_variant<10, 16, 64, 1, 2, 7>(dev, P, B, n, iters, rv); break;
-    case 6: launch_run_variant<12, 16, 64, 2, 1, 5>(dev, P, B, n, iters, rv); break;
-    case 7: launch_run_variant<12, 16, 64, 1, 1, 5>(dev, P, B, n, iters, rv); break;
+    case 2: launch_run_variant<10, 8, 64, 1, 1, 7>(dev, P, B, n, iters, rv); break;
+    case 3: launch_run_variant<10, 24, 64, 1, 1, 7>(dev, P, B, n, iters, rv); break;
+    case 4: launch_run_variant<10, 32, 64, 1, 1, 7>(dev, P, B, n, iters, rv); break;
+    case 5: launch_run_variant<8, 16, 64, 1, 1, 7>(dev, P, B, n, iters, rv); break;
+    case 6: launch_run_variant<10, 12, 64, 1, 1, 7>(dev, P, B, n, iters, rv); break;
+    case 7: launch_run_variant<10, 20, 64, 1, 1, 7>(dev, P, B, n, iters, rv); break;
     case 8: launch_run_variant<12, 16, 64, 1, 2, 6>(dev, P, B, n, iters, rv); break;
     case 9: launch_run_variant<12, 16, 64, 1, 2, 5>(dev, P, B, n, iters, rv); break;   // = RT_SCHEDULE_TWO_LEAF_SLOTS
     case 10: launch_run_variant<12, 16, 64, 2, 2, 5>(dev, P, B, n, iters, rv); break;
