@@ -136,13 +136,12 @@ struct Hit { uint32_t tri; float t, u, v; };
 // data-dependent loops (pop / descend / leaf), which on a 64-wide wave leaves
 // most lanes waiting for the longest one at every level.  Here every lane is a
 // small state machine and the wave runs ONE flat loop: per trip, lanes that sit
-// on an interior node take one descend step, lanes that sit in a leaf test one
-// triangle (and pop when the leaf is used up), and lanes whose ray has finished
-// are handed new rays from a global work counter once enough of them are idle
-// (ballot + prefix rank).  Everything a lane needs for its step -- the node it
-// stands on, or the next triangle of its leaf -- is fetched by all lanes
-// together at the top of the trip, so a trip costs one memory round trip
-// shared by all 64 lanes.
+// on an interior node fetch its record and descend (up to two levels, the
+// record holds the node's interior children as well), then lanes that sit in a
+// leaf fetch and test one triangle (and pop when the leaf is used up), and
+// lanes whose ray has finished are handed new rays from a global work counter
+// once enough of them are idle (ballot + prefix rank).  Loads are exec-masked:
+// only the lanes that step pay for a cache lookup.
 //
 // Stack entries are {far child, t_split}: an entry's t_max always equals the
 // t_split of the entry below it (scene_t_max for the bottom one), so it is not
@@ -1109,12 +1108,9 @@ void launch_kd_intersect(rt_device *dev, const TravScene &P, const float4 *ro, c
         variant = e ? atoi(e) : 0;
     }
     switch (variant) {
-    case 1: launch_kd_variant<12, 16, 256>(dev, P, ro, rd, hits, n); break;
-    case 2: launch_kd_variant<16, 32, 256>(dev, P, ro, rd, hits, n); break;
-    case 3: launch_kd_variant<8, 16, 256>(dev, P, ro, rd, hits, n); break;
-    case 4: launch_kd_variant<16, 8, 256>(dev, P, ro, rd, hits, n); break;
-    case 5: launch_kd_variant<10, 24, 512>(dev, P, ro, rd, hits, n); break;
-    default: launch_kd_variant<16, 16, 256>(dev, P, ro, rd, hits, n); break;
+    case 1: launch_kd_variant<16, 16, 256>(dev, P, ro, rd, hits, n); break;
+    case 2: launch_kd_variant<8, 16, 256>(dev, P, ro, rd, hits, n); break;
+    default: launch_kd_variant<12, 16, 256>(dev, P, ro, rd, hits, n); break;
     }
 }
 
