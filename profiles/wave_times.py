@@ -1,0 +1,27 @@
+"""Diagnostic build only (make EXTRA_HIPFLAGS=-DRT_WAVE_TIMES): when do the waves of one 50-iteration launch start,
+see the work queue run dry, and exit?  Times in ms from the first wave's start (100 MHz wall clock)."""
+import sys
+sys.path.insert(0, '.')
+import numpy as np
+import raytracer_amd as rt
+sc = rt.scenes.icosphere_scene(8)
+W = H = 2048
+r = rt.Renderer(sc, W, H).build()
+r.init_spath(seed=1, resolve_interval=50, quiet=True, schedule=0)
+r.spath_prepass(num_iterations=1 << 30)
+r.spath_render(100); r.sync()
+r.spath_render(50); r.sync()
+n = W * H
+raw = r.download(r.spath.contents.cl_pixel_cost_buffer, np.uint32, n + 65536)[n:].reshape(-1, 4)
+raw = raw[:7168]
+t0 = raw[:, 0].min()
+start, end, dry, trips = [(raw[:, k] - t0).astype(np.int64) / 1e5 for k in (0, 1, 2)] + [raw[:, 3]]
+pct = [0, 1, 10, 50, 90, 99, 100]
+print("waves", len(raw))
+print("start  ms", np.percentile(start, pct).round(2))
+print("dry    ms", np.percentile(dry, pct).round(2))
+print("exit   ms", np.percentile(end, pct).round(2))
+print("exit - dry ms", np.percentile(end - dry, pct).round(2))
+print("trips", np.percentile(trips, pct).round(0))
+alive = [(end > t).sum() for t in np.linspace(0, end.max(), 21)]
+print("waves alive at 5% steps of the launch:", alive)

@@ -77,7 +77,7 @@ spath_raytracer_context *init_spath_raytracer_context(struct _rt_ctx *rctx)
     c->pending = 0;
     c->pending_values = (unsigned int *)malloc(sizeof(unsigned int) * 1024);
     c->cl_random_value_buffer = rt_mem_alloc(dev, sizeof(unsigned int) * 1024);
-    c->cl_pixel_cost_buffer = rt_mem_alloc(dev, n * sizeof(unsigned int));
+    c->cl_pixel_cost_buffer = rt_mem_alloc(dev, ((size_t)n + 65536) * sizeof(unsigned int));   /* + room for a diagnostic build's per-wave time stamps */
     c->cl_pixel_order_buffer = rt_mem_alloc(dev, n * sizeof(unsigned int));
     c->cl_cost_hist_buffer = rt_mem_alloc(dev, 256 * sizeof(unsigned int));
     c->order_valid = false;

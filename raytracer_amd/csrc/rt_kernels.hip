@@ -333,16 +333,6 @@ __device__ __forceinline__ uint32_t queue_take(WorkQueue &q, bool want, uint32_t
     const unsigned long long mask = __ballot(want);
     const uint32_t nwant = (uint32_t)__popcll(mask);
     if (q.exhausted || nwant == 0) return ~0u;
-    if (CHUNK == 0) {
-        // claim exactly what the wave needs now
-        uint32_t base = 0;
-        if (threadIdx.x == 0) base = atomicAdd(counter, nwant);
-        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-        if (base >= n) { q.exhausted = true; return ~0u; }
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-        if (n - base <= nwant) q.exhausted = true;
-        return (want && rank < n - base) ? base + rank : ~0u;
-    }
     if (q.next >= q.end) {
         uint32_t base = 0;
         if (threadIdx.x == 0) base = atomicAdd(counter, (uint32_t)CHUNK);
@@ -637,6 +627,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
     Walk w = {};
     f3 o = mk3(0.f, 0.f, 0.f), d = o;
     uint32_t mode = FREE, pix = 0, it = 0, rnd = 0, steps = 0;
+#ifdef RT_WAVE_TIMES
+    if (threadIdx.x == 0 && blockIdx.x < 16384) B.cost[n + 4 * blockIdx.x] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+    uint32_t exhausted_at = 0, trips = 0;
+#endif
     float4 pa = make_float4(0, 0, 0, 0), pb = pa;
 
     for (;;) {
@@ -688,6 +682,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
             // (c) start the walk of every new ray
             if (fresh) mode = walk_begin(P, w, o, d) ? WALK : DONE;
         }
+#ifdef RT_WAVE_TIMES
+        trips++;
+        if (q.exhausted && !exhausted_at) exhausted_at = (uint32_t)__builtin_amdgcn_s_memrealtime();
+#endif
         if (!__any(mode == WALK)) {
             if (q.exhausted && !__any(mode == DONE)) break;
             continue;
@@ -710,6 +708,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
             }
         }
     }
+#ifdef RT_WAVE_TIMES
+    if (threadIdx.x == 0 && blockIdx.x < 16384) {
+        B.cost[n + 4 * blockIdx.x + 1] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+        B.cost[n + 4 * blockIdx.x + 2] = exhausted_at;
+        B.cost[n + 4 * blockIdx.x + 3] = trips;
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------
