@@ -340,12 +340,13 @@ def obj_parse(data: bytes) -> dict:
     return out
 
 
-def load_scene(url: str, resource_root: str) -> "scenes.SceneArrays":
+def load_scene(url: str | None, resource_root: str, text: str | None = None) -> "scenes.SceneArrays":
     """A .rsc scene file (and the OBJ meshes it names, both relative to
-    `resource_root`) through load_scene_json_url, copied into SceneArrays."""
+    `resource_root`) through load_scene_json_url -- or, with `text`, a scene
+    description held in memory through load_scene_json -- copied into SceneArrays."""
     L = lib()
     L.rt_set_resource_root(resource_root.encode())
-    sp = L.load_scene_json_url(url.encode())
+    sp = L.load_scene_json(text.encode()) if text is not None else L.load_scene_json_url(url.encode())
     s = sp.contents
 
     def rec(ptr, n, dt):

@@ -61,6 +61,29 @@ def test_reference_obj_mesh_if_present(rt, orc):
     assert (hk.blob == kt.blob[:kt.blob_size]).all()
 
 
+@pytest.mark.parametrize("case", ["scene:scenes/path_obj.rsc", "mesh:mesh/test3.obj", "mesh:mesh/scene3_1.obj"])
+def test_reference_scenes_through_loader_and_all_three_builders(rt, orc, case):
+    """The reference's own scene files and its largest mesh (46,966 triangles), read by the library's loader, then
+    the REFERENCE's builder against the oracle's and the product's: same serialised tree."""
+    root = "/root/reference/res"
+    if orc.ref_lib() is None or not os.path.isdir(root):
+        pytest.skip("reference checkout not present")
+    kind, url = case.split(":")
+    if kind == "scene":
+        sc = rt.load_scene(url, root)
+    else:
+        sc = rt.load_scene(None, root, text='{"name":"m","materials":[{"r":1,"g":1,"b":1,"reflectivity":0.5}],'
+                                            '"meshes":[{"url":"%s","mat_index":0}],"primitives":{}}' % url)
+    assert sc.num_tris > 10000
+    kt = orc.KdTree(sc.verts4, sc.idx4)
+    blob, counts, bounds = orc.ref_kd_blob(sc.verts4, sc.idx4)
+    assert [kt.counts[k] for k in ("nodes_total", "traversal", "leaves", "indices_total", "tris_padded")] == list(counts)
+    m = orc.blob_significant_mask(kt.blob, kt.blob_used)
+    assert (kt.blob[m] == blob[m]).all()
+    hk = rt.HostKdTree(sc)
+    assert (hk.blob == kt.blob[:kt.blob_size]).all()
+
+
 @pytest.mark.parametrize("name", ["ico2", "ico4", "soup2k", "mixed"])
 @pytest.mark.parametrize("threads", [1, 4])
 def test_product_builder_matches_oracle(rt, orc, name, threads):
