@@ -10,6 +10,9 @@ spath_ico3.npz  oracle outputs for a 48x32 render of icosphere_scene(3):
               counter-based RNG streams (seed 11).  These pin the oracle against
               its own earlier output (the reference has no vectors for the
               kernels), so a change in them is a deliberate, reviewed event.
+ss_sphere_plane.npz  oracle outputs for the sphere + plane scene of res/scenes/path_test.rsc at 96x64: the
+              SS integrator's packed image and the PATH integrator's first sample (regression only,
+              like spath_ico3.npz).
 obj_cases.npz  small hand-written OBJ texts (quads and n-gons, negative and missing
               indices, CRLF and lone-CR line endings, a last line without line ending,
               groups before / between / after faces, signs and positive exponents)
@@ -48,6 +51,11 @@ def main():
     np.savez_compressed(os.path.join(HERE, "spath_ico3.npz"), source_results=st.source_results,
                         out_tex=st.out_tex, progress=st.progress, rays=st.rays, image=st.resolve(),
                         scene_sha256=hashlib.sha256(sc.verts4.tobytes() + sc.idx4.tobytes()).hexdigest())
+    sc = scenes.sphere_plane_scene()
+    rays = orc.generate_rays(96, 64)
+    np.savez_compressed(os.path.join(HERE, "ss_sphere_plane.npz"), image=orc.cast_ray_test(sc, rays),
+                        first_sample=orc.path_trace(sc, rays, 96, 64, (0, 0, 0), 1))
+
     cases = obj_cases()
     arrays = {}
     for name, text in cases.items():

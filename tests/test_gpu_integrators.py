@@ -45,3 +45,21 @@ def test_path_trace_within_tolerance(rt, orc):
             assert_bits_equal(got_out, out, "running mean")
             assert_bits_equal(img, orc.f_to_byte(out), "packed image")
     r.close()
+
+
+def test_config1_full_size(rt, orc):
+    """The reference's default sphere + plane scene at 512x512, one SS frame (primary, shadow and two mirror bounces
+    per pixel): the whole image bit for bit, and the PATH integrator's first sample within its tolerance."""
+    sc = rt.scenes.sphere_plane_scene()
+    w = h = 512
+    r = rt.Renderer(sc, w, h).build()
+    img = r.ss_render()
+    rays = orc.generate_rays(w, h)
+    assert_bits_equal(img, orc.cast_ray_test(sc, rays), "cast_ray_test image")
+    assert len(np.unique(img)) > 20
+    r.init_path(num_samples=1)
+    r.path_render()
+    fresh = orc.path_trace(sc, rays, w, h, (0, 0, 0), 1)
+    got = r.download(r.path.contents.cl_path_fresh_frame_buffer, np.float32, 4 * w * h).reshape(-1, 4)
+    assert (got.view(np.uint32) != fresh.view(np.uint32)).any(axis=1).mean() <= 0.005
+    r.close()
