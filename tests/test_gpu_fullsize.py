@@ -114,3 +114,51 @@ def test_soup_scene_strip_against_oracle(rt, orc):
     assert_bits_equal(g["progress"], st.progress, "progress")
     assert_bits_equal(g["out_tex"], st.out_tex, "out_tex")
     r.close()
+
+
+def test_config2_full_frame_both_launch_structures(rt):
+    """82 k-triangle scene at 1024x1024 (the ~70 k-triangle configuration): 64 iterations batched (with the
+    schedule trial and pixel reordering on their defaults) against one launch per kernel per iteration."""
+    sc = rt.scenes.icosphere_scene(6)
+    w = h = 1024
+    a = rt.Renderer(sc, w, h).build()
+    a.init_spath(seed=5, resolve_interval=50, quiet=True)
+    a.spath_prepass(num_iterations=1 << 30)
+    a.spath_render(64)
+    b = rt.Renderer(sc, w, h).build()
+    b.init_spath(seed=5, separate_kernels=True, resolve_interval=50, quiet=True)
+    b.spath_prepass(num_iterations=1 << 30)
+    b.spath_render(64)
+    n = w * h
+    ba, bb = a.spath_buffers(), b.spath_buffers()
+    for name, words in (("ray_o", 4), ("ray_d", 4), ("hits", 4), ("prog_a", 4), ("prog_b", 4), ("random", 1),
+                        ("out_tex", 4)):
+        assert_bits_equal(a.download(getattr(ba, name), np.uint32, words * n),
+                          b.download(getattr(bb, name), np.uint32, words * n), name)
+    # the frame the caller saw at the last resolve point (iteration 50) is the same too
+    assert_bits_equal(a.output, b.output, "frame at the resolve point")
+    assert a.spath.contents.trial_state == 2
+    a.close(); b.close()
+
+
+def test_config5_size_strip_against_oracle(rt, orc):
+    """10 M-triangle soup, four rows through the middle of a 3840x2160 frame: tree flattening at that size
+    (11 M nodes, 30 M leaf slots), long leaves, the two-leaf-slot schedule, against the oracle."""
+    sc = rt.scenes.soup_scene(10_000_000)
+    w, full_h, y0, rows, iters = 3840, 2160, 1078, 4, 5
+    for schedule in (1, 0):
+        r = rt.Renderer(sc, w, rows, tile_y0=y0, full_height=full_h).build()
+        r.init_spath(seed=8, resolve_interval=0, quiet=True, schedule=schedule)
+        r.spath_prepass(num_iterations=1 << 30)
+        r.spath_render(iters)
+        if schedule == 1:
+            tree = _oracle_tree(orc, r, sc)
+            st = oracle_spath_run(orc, sc, tree, w, rows, 8, iters, y0=y0, full_h=full_h)
+            del tree
+        g = r.spath_state()
+        hits_equal(g["source_results"], st.source_results, "primary hits")
+        hits_equal(g["results"], st.results, "bounce hits")
+        assert_bits_equal(g["progress"], st.progress, "progress")
+        assert_bits_equal(g["out_tex"], st.out_tex, "out_tex")
+        r.close()
+    assert (st.source_results["t"] != 0).mean() > 0.3
