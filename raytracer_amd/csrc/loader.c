@@ -705,7 +705,7 @@ scene *load_scene_json(char *json)
             /* src/loader.c:203-225: three floats per element into four-float slots */
             for (unsigned int v = 0; v < o->num_vertices; v++) memcpy(s->mesh_verts + vert_off++, o->vertices + 3 * (size_t)v, 3 * sizeof(float));
             for (unsigned int v = 0; v < o->num_normals; v++) memcpy(s->mesh_nrmls + nrml_off++, o->normals + 3 * (size_t)v, 3 * sizeof(float));
-            memcpy(s->mesh_texcoords + tex_off, o->texcoords, sizeof(vec2) * (size_t)o->num_texcoords);
+            if (o->num_texcoords) memcpy(s->mesh_texcoords + tex_off, o->texcoords, sizeof(vec2) * (size_t)o->num_texcoords);
             tex_off += o->num_texcoords;
         }
         printf("%i and %i\n", (int)vert_off, (int)s->num_mesh_verts);
