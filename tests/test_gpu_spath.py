@@ -312,3 +312,27 @@ def test_kd_intersect_arbitrary_rays(rt, orc, small):
     for m in (ro, rd, hits):
         r.L.rt_mem_free(r.dev, m)
     r.close()
+
+
+def test_default_rng_mode_renders_the_same_picture(rt, tmp_path):
+    """Without a seed the library draws from srand(clock) / rand() like the reference: not reproducible, but the
+    converged picture must be the same as the seeded one up to noise."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(rt.LIB_PATH), "rt_headless")
+    url = rt.scenes.write_rsc(rt.scenes.icosphere_scene(3), str(tmp_path), "ico3")
+    w, h, samples = 64, 48, 24
+    frames = []
+    for name, extra in (("seeded", {"RT_RNG_SEED": "3"}), ("libc", {})):
+        out = tmp_path / f"{name}.ppm"
+        env = {k: v for k, v in os.environ.items() if k != "RT_RNG_SEED"}
+        env.update(extra)
+        p = subprocess.run([exe, str(tmp_path), url, str(w), str(h), str(samples), str(out), "spath"], env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+        assert p.returncode == 0, p.stderr.decode()[-1500:]
+        raw = out.read_bytes()
+        frames.append(np.frombuffer(raw[len(f"P6\n{w} {h}\n255\n"):], np.uint8).astype(np.float64))
+    a, b = frames
+    assert not np.array_equal(a, b)                       # different random streams
+    assert abs(a.mean() - b.mean()) < 0.05 * a.mean()     # same picture
+    assert np.sqrt(np.mean((a - b) ** 2)) < 40            # per-pixel noise of 24 samples, not a different image
