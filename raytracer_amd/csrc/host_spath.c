@@ -162,10 +162,11 @@ void spath_raytracer_flush(spath_raytracer_context *c)
                        c->cl_pixel_cost_buffer, order, c->schedule);
     }
     if (!c->no_reorder && n >= 65536) {
-        /* the next batch serves the pixels that were heaviest in this one first;
-           bucket width ~ 1/64 of a typical pixel's cost (about 32 steps per iteration) */
+        /* the next batch serves the pixels that were heaviest in this one first; bucket width ~ 1/16 of a
+           typical pixel's cost (about 32 steps per iteration): finer buckets order better but scatter the
+           pixels of a screen tile over more chunks, and the rays of a chunk then diverge more */
         unsigned int shift = 0;
-        while ((32u * c->pending) >> shift > 64u) shift++;
+        while ((32u * c->pending) >> shift > 16u) shift++;
         rt_k_pixel_order(dev, c->cl_pixel_cost_buffer, c->cl_pixel_order_buffer, c->cl_cost_hist_buffer, n, shift,
                          rctx->width);
         c->order_valid = true;
