@@ -198,14 +198,16 @@ void rt_k_xorshift(rt_device *dev, rt_mem random, uint32_t n);
 void rt_k_spath_run(rt_device *dev, const rt_kd_view *kd, const rt_spath_buffers *b, uint32_t n, uint32_t iters,
                     rt_mem random_values, rt_mem cost, rt_mem order, int schedule);
 
-/* Pixel indices sorted by decreasing cost >> shift (counting sort, 256 buckets)
-   into order[0..n); hist256 is 256 words of scratch.  Pixels of equal bucket
-   keep screen-tile order (8x8 tiles of a frame `width` pixels wide) when width
-   and n / width are multiples of 8, index order otherwise (width 0: always).
-   No counterpart in the reference: it only feeds the scheduling of the next
-   rt_k_spath_run. */
+/* The order in which the next rt_k_spath_run hands pixels to lanes: heaviest
+   first, by cost >> shift (counting sort, 256 buckets), into order[0..n);
+   hist256 is 256 words of scratch.  When the frame (`width` pixels wide, n /
+   width rows) divides into 8x8 screen tiles and tile_scratch (2 * n / 64 words)
+   is given, whole tiles are sorted by their mean cost and each tile's 64 pixels
+   stay together; otherwise single pixels are sorted (ties in screen-tile order
+   when the frame divides into tiles, index order if not or if width is 0).
+   No counterpart in the reference: scheduling only. */
 void rt_k_pixel_order(rt_device *dev, rt_mem cost, rt_mem order, rt_mem hist256, uint32_t n, uint32_t shift,
-                      uint32_t width);
+                      uint32_t width, rt_mem tile_scratch);
 
 /* f_buffer_to_byte_buffer_avg (src/kernels/path.cl:428-444; host src/spath_raytracer.c:252-277). */
 void rt_k_resolve_avg(rt_device *dev, rt_mem out_u32, rt_mem out_tex, uint32_t n);

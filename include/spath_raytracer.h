@@ -55,14 +55,15 @@ typedef struct spath_raytracer_context {
     rt_mem       cl_pixel_cost_buffer;   /* walk steps per pixel in the last batch */
     rt_mem       cl_pixel_order_buffer;  /* pixels by decreasing cost: service order of the next batch */
     rt_mem       cl_cost_hist_buffer;
+    rt_mem       cl_tile_scratch_buffer; /* per-tile cost and order (2 * pixels / 64 words) */
     bool         order_valid;
     int          no_reorder;             /* 1: always serve pixels in index order */
     int          schedule;               /* RT_SCHEDULE_* the batches run with */
     int          schedule_fixed;         /* 1: keep `schedule`; 0: the first batch of a render that is long enough is
                                             split in two launches, one per schedule, and the faster one is kept */
     int          trial_state;            /* 0: not tried yet, 1: trial queued, 2: decided */
-    rt_event     trial_marks[3];
-    unsigned int trial_iters[2];
+    rt_event     trial_marks[4];
+    unsigned int trial_iters[3];
 } spath_raytracer_context;
 
 spath_raytracer_context *init_spath_raytracer_context(struct _rt_ctx *rctx);   /* src/spath_raytracer.c:39-116 */

@@ -136,9 +136,10 @@ class spath_raytracer_context(C.Structure):
                 ("quiet", C.c_bool), ("max_batch", C.c_uint), ("pending", C.c_uint),
                 ("pending_values", C.POINTER(C.c_uint)), ("cl_random_value_buffer", C.c_void_p),
                 ("cl_pixel_cost_buffer", C.c_void_p), ("cl_pixel_order_buffer", C.c_void_p),
-                ("cl_cost_hist_buffer", C.c_void_p), ("order_valid", C.c_bool), ("no_reorder", C.c_int),
+                ("cl_cost_hist_buffer", C.c_void_p), ("cl_tile_scratch_buffer", C.c_void_p),
+                ("order_valid", C.c_bool), ("no_reorder", C.c_int),
                 ("schedule", C.c_int), ("schedule_fixed", C.c_int), ("trial_state", C.c_int),
-                ("trial_marks", C.c_void_p * 3), ("trial_iters", C.c_uint * 2)]
+                ("trial_marks", C.c_void_p * 4), ("trial_iters", C.c_uint * 3)]
 
 
 class rt_device_props(C.Structure):
@@ -260,7 +261,7 @@ def lib():
     L.rt_k_spath_trace.argtypes = [vp, C.POINTER(rt_kd_view), C.POINTER(rt_spath_buffers), u32, u32, C.c_int]
     L.rt_k_xorshift.argtypes = [vp, vp, u32]
     L.rt_k_spath_run.argtypes = [vp, C.POINTER(rt_kd_view), C.POINTER(rt_spath_buffers), u32, u32, vp, vp, vp, C.c_int]
-    L.rt_k_pixel_order.argtypes = [vp, vp, vp, vp, u32, u32, u32]
+    L.rt_k_pixel_order.argtypes = [vp, vp, vp, vp, u32, u32, u32, vp]
     L.rt_k_resolve_avg.argtypes = [vp, vp, vp, u32]
     L.rt_k_f_buffer_average.argtypes = [vp, vp, vp, u32, u32]
     L.rt_k_f_to_byte.argtypes = [vp, vp, vp, u32]

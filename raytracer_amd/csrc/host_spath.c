@@ -80,6 +80,9 @@ spath_raytracer_context *init_spath_raytracer_context(struct _rt_ctx *rctx)
     c->cl_pixel_cost_buffer = rt_mem_alloc(dev, ((size_t)n + 65536) * sizeof(unsigned int));   /* + room for a diagnostic build's per-wave time stamps */
     c->cl_pixel_order_buffer = rt_mem_alloc(dev, n * sizeof(unsigned int));
     c->cl_cost_hist_buffer = rt_mem_alloc(dev, 256 * sizeof(unsigned int));
+    /* whole 8x8 screen tiles are ordered when the frame divides into them */
+    c->cl_tile_scratch_buffer = (rctx->width % 8 == 0 && rctx->height % 8 == 0)
+                                    ? rt_mem_alloc(dev, 2 * (size_t)(n / 64) * sizeof(unsigned int)) : NULL;
     c->order_valid = false;
     c->no_reorder = 0;
     return c;
@@ -106,19 +109,22 @@ static void upload_random_buffer(spath_raytracer_context *c)
     rt_mem_upload(rctx->rcl->device, c->cl_random_buffer, c->random_buffer, n * sizeof(unsigned int));
 }
 
-/* Reads the two timings of a queued schedule trial (waits for the launches) and keeps the faster schedule; the
-   second one has to win by 5 % to displace the default. */
+/* Reads the timings of a queued schedule trial (waits for the launches) and keeps the faster schedule.  The
+   trial ran default / alternative / default; the alternative has to beat the better of the two default runs by
+   5 % to displace it, so a slow first launch (cold caches, clocks still ramping) cannot decide it. */
 static void finish_schedule_trial(spath_raytracer_context *c)
 {
     if (c->trial_state != 1) return;
     rt_device *dev = c->rctx->rcl->device;
-    const float a = rt_event_elapsed_ms(dev, c->trial_marks[0], c->trial_marks[1]) / (float)c->trial_iters[0];
-    const float b = rt_event_elapsed_ms(dev, c->trial_marks[1], c->trial_marks[2]) / (float)c->trial_iters[1];
-    c->schedule = (b < 0.95f * a) ? RT_SCHEDULE_TWO_LEAF_SLOTS : RT_SCHEDULE_ONE_LEAF_SLOT;
-    for (int k = 0; k < 3; k++) { rt_event_release(dev, c->trial_marks[k]); c->trial_marks[k] = NULL; }
+    float t[3];
+    for (int k = 0; k < 3; k++)
+        t[k] = rt_event_elapsed_ms(dev, c->trial_marks[k], c->trial_marks[k + 1]) / (float)c->trial_iters[k];
+    const float a = t[0] < t[2] ? t[0] : t[2];
+    c->schedule = (t[1] < 0.95f * a) ? RT_SCHEDULE_TWO_LEAF_SLOTS : RT_SCHEDULE_ONE_LEAF_SLOT;
+    for (int k = 0; k < 4; k++) { rt_event_release(dev, c->trial_marks[k]); c->trial_marks[k] = NULL; }
     c->trial_state = 2;
     if (!c->quiet)
-        printf("schedule trial: %.3f / %.3f ms per iteration -> %s\n", a, b,
+        printf("schedule trial: %.3f / %.3f / %.3f ms per iteration -> %s\n", t[0], t[1], t[2],
                c->schedule == RT_SCHEDULE_TWO_LEAF_SLOTS ? "two leaf slots" : "one leaf slot");
 }
 
@@ -138,24 +144,28 @@ void spath_raytracer_flush(spath_raytracer_context *c)
         /* nothing is known about costs yet: all pixels in one bucket, i.e. plain screen-tile order */
         rt_mem_zero(dev, c->cl_pixel_cost_buffer, sizeof(unsigned int) * (size_t)n);
         rt_k_pixel_order(dev, c->cl_pixel_cost_buffer, c->cl_pixel_order_buffer, c->cl_cost_hist_buffer, n, 0,
-                         rctx->width);
+                         rctx->width, c->cl_tile_scratch_buffer);
         c->order_valid = true;
     }
     finish_schedule_trial(c);
     const rt_mem order = (c->order_valid && !c->no_reorder) ? c->cl_pixel_order_buffer : NULL;
+    unsigned int cost_iters = c->pending;      /* iterations the cost buffer will describe: those of the last launch */
     if (!c->schedule_fixed && c->trial_state == 0 && c->pending >= 16 && n >= 65536) {
-        /* the two halves of this batch run under one schedule each, back to back, in the same pixel order */
-        const unsigned int half = c->pending / 2;
-        c->trial_iters[0] = half;
-        c->trial_iters[1] = c->pending - half;
+        /* three parts of this batch, back to back in the same pixel order: default, alternative, default */
+        static const int part_schedule[3] = { RT_SCHEDULE_ONE_LEAF_SLOT, RT_SCHEDULE_TWO_LEAF_SLOTS,
+                                              RT_SCHEDULE_ONE_LEAF_SLOT };
+        unsigned int done = 0;
         c->trial_marks[0] = rt_event_record(dev);
-        rt_k_spath_run(dev, &rctx->stat_scene->kdt->view, &b, n, half, c->cl_random_value_buffer,
-                       c->cl_pixel_cost_buffer, order, RT_SCHEDULE_ONE_LEAF_SLOT);
-        c->trial_marks[1] = rt_event_record(dev);
-        rt_k_spath_run(dev, &rctx->stat_scene->kdt->view, &b, n, c->pending - half,
-                       (char *)c->cl_random_value_buffer + sizeof(unsigned int) * half,
-                       c->cl_pixel_cost_buffer, order, RT_SCHEDULE_TWO_LEAF_SLOTS);
-        c->trial_marks[2] = rt_event_record(dev);
+        for (int k = 0; k < 3; k++) {
+            const unsigned int part = (c->pending - done) / (unsigned int)(3 - k);
+            c->trial_iters[k] = part;
+            rt_k_spath_run(dev, &rctx->stat_scene->kdt->view, &b, n, part,
+                           (char *)c->cl_random_value_buffer + sizeof(unsigned int) * done,
+                           c->cl_pixel_cost_buffer, order, part_schedule[k]);
+            c->trial_marks[k + 1] = rt_event_record(dev);
+            done += part;
+            cost_iters = part;
+        }
         c->trial_state = 1;
     } else {
         rt_k_spath_run(dev, &rctx->stat_scene->kdt->view, &b, n, c->pending, c->cl_random_value_buffer,
@@ -166,9 +176,9 @@ void spath_raytracer_flush(spath_raytracer_context *c)
            typical pixel's cost (about 32 steps per iteration): finer buckets order better but scatter the
            pixels of a screen tile over more chunks, and the rays of a chunk then diverge more */
         unsigned int shift = 0;
-        while ((32u * c->pending) >> shift > 16u) shift++;
+        while ((32u * cost_iters) >> shift > 16u) shift++;
         rt_k_pixel_order(dev, c->cl_pixel_cost_buffer, c->cl_pixel_order_buffer, c->cl_cost_hist_buffer, n, shift,
-                         rctx->width);
+                         rctx->width, c->cl_tile_scratch_buffer);
         c->order_valid = true;
     }
     c->pending = 0;
@@ -289,6 +299,7 @@ void spath_raytracer_destroy(spath_raytracer_context *c)
     rt_mem_free(dev, c->cl_pixel_cost_buffer);
     rt_mem_free(dev, c->cl_pixel_order_buffer);
     rt_mem_free(dev, c->cl_cost_hist_buffer);
+    if (c->cl_tile_scratch_buffer) rt_mem_free(dev, c->cl_tile_scratch_buffer);
     free(c->pending_values);
     free(c->random_buffer);
     free(c);

@@ -795,6 +795,28 @@ __global__ __launch_bounds__(256) void k_cost_scatter(const uint32_t *__restrict
     }
 }
 
+// Tile-granular order: whole 8x8 screen tiles sorted by their mean cost, each
+// tile's 64 pixels kept together.  A wave's 64-item chunk is then exactly one
+// tile, whose rays start next to each other and diverge least; ordering single
+// pixels balances the launch slightly better but costs 10 % in divergence.
+__global__ __launch_bounds__(256) void k_tile_cost(const uint32_t *__restrict__ cost, uint32_t n_tiles, uint32_t tiles_per_row,
+                                                    uint32_t *__restrict__ tcost)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tiles) return;
+    uint32_t sum = 0;
+    for (uint32_t k = 0; k < 64u; k++) sum += cost[tile_pixel(t * 64u + k, tiles_per_row)];
+    tcost[t] = sum >> 6;
+}
+
+__global__ __launch_bounds__(256) void k_tile_expand(const uint32_t *__restrict__ torder, uint32_t n, uint32_t tiles_per_row,
+                                                      uint32_t *__restrict__ order)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    order[i] = tile_pixel(torder[i >> 6] * 64u + (i & 63u), tiles_per_row);
+}
+
 // xorshift_batch, reference: src/kernels/path.cl:421-426
 __global__ void k_xorshift(uint32_t *__restrict__ data, uint32_t n)
 {
@@ -1256,13 +1278,28 @@ void rt_k_xorshift(rt_device *dev, rt_mem random, uint32_t n)
 }
 
 void rt_k_pixel_order(rt_device *dev, rt_mem cost, rt_mem order, rt_mem hist256, uint32_t n, uint32_t shift,
-                      uint32_t width)
+                      uint32_t width, rt_mem tile_scratch)
 {
     if (!n) return;
     uint32_t tiles_per_row = 0;
     if (width && width % 8u == 0 && n % width == 0 && (n / width) % 8u == 0) tiles_per_row = width / 8u;
     rt_launch_timer tm(dev, RT_K_PIXEL_ORDER);
     RT_HIP_CHECK(hipMemsetAsync(hist256, 0, RT_COST_BUCKETS * sizeof(uint32_t), dev->stream));
+    if (tile_scratch && tiles_per_row) {
+        const uint32_t n_tiles = n / 64u;
+        uint32_t *tcost = (uint32_t *)tile_scratch, *torder = tcost + n_tiles;
+        hipLaunchKernelGGL(k_tile_cost, dim3(blocks_for(n_tiles, 256)), dim3(256), 0, dev->stream, (const uint32_t *)cost,
+                           n_tiles, tiles_per_row, tcost);
+        hipLaunchKernelGGL(k_cost_hist, dim3(blocks_for(n_tiles, 1024)), dim3(256), 0, dev->stream, (const uint32_t *)tcost,
+                           n_tiles, shift, 0u, (uint32_t *)hist256);
+        hipLaunchKernelGGL(k_cost_scan, dim3(1), dim3(256), 0, dev->stream, (uint32_t *)hist256);
+        hipLaunchKernelGGL(k_cost_scatter, dim3(blocks_for(n_tiles, 1024)), dim3(256), 0, dev->stream,
+                           (const uint32_t *)tcost, n_tiles, shift, 0u, (uint32_t *)hist256, torder);
+        hipLaunchKernelGGL(k_tile_expand, dim3(blocks_for(n, 256)), dim3(256), 0, dev->stream, (const uint32_t *)torder, n,
+                           tiles_per_row, (uint32_t *)order);
+        RT_AFTER_LAUNCH();
+        return;
+    }
     hipLaunchKernelGGL(k_cost_hist, dim3(blocks_for(n, 1024)), dim3(256), 0, dev->stream, (const uint32_t *)cost, n,
                        shift, tiles_per_row, (uint32_t *)hist256);
     hipLaunchKernelGGL(k_cost_scan, dim3(1), dim3(256), 0, dev->stream, (uint32_t *)hist256);
