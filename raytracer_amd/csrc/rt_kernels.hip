@@ -102,21 +102,22 @@ __device__ __forceinline__ uint32_t get_colour(float x, float y, float z, float 
 }
 
 // Moeller-Trumbore with back-face culling on precomputed edges,
-// reference: src/kernels/collision.cl:139-172
+// reference: src/kernels/collision.cl:139-172.  The reference returns at the
+// first failed test; here every lane computes all of it and the tests are
+// combined at the end (the values a failed test leaves behind are never
+// used), which keeps the wave on one straight instruction stream.
 __device__ __forceinline__ bool tri_hit_edges(f3 v0, f3 ab, f3 ac, f3 o, f3 d, float &t, float &u, float &v)
 {
-    f3 pvec = cross3(d, ac);
-    float det = dot3(ab, pvec);
-    if (det < RT_EPS) return false;
-    float inv = 1.f / det;
-    f3 tvec = o - v0;
+    const f3 pvec = cross3(d, ac);
+    const float det = dot3(ab, pvec);
+    const float inv = 1.f / det;
+    const f3 tvec = o - v0;
     u = dot3(tvec, pvec) * inv;
-    if (u < 0 || u > 1) return false;
-    f3 qvec = cross3(tvec, ab);
+    const f3 qvec = cross3(tvec, ab);
     v = dot3(d, qvec) * inv;
-    if (v < 0 || u + v > 1) return false;
     t = dot3(ac, qvec) * inv;
-    return true;
+    const bool miss = (det < RT_EPS) | (u < 0) | (u > 1) | (v < 0) | (u + v > 1);
+    return !miss;
 }
 
 struct Hit { uint32_t tri; float t, u, v; };
@@ -210,19 +211,20 @@ __device__ __forceinline__ void walk_descend(Walk &w, f3 o, f3 d, uint32_t k, fl
     const float ok = ((k == 0) ? o.x : ((k == 1) ? o.y : o.z)) + 0.0f;
     const float dk = ((k == 0) ? d.x : ((k == 1) ? d.y : d.z)) + 0.0f;
     const float t_split = (b - ok) / dk;
-    const bool left_close = (ok < b) || (ok == b && dk <= 0);
+    const bool left_close = (ok < b) | ((ok == b) & (dk <= 0));
     const uint32_t first = left_close ? left : right;
     const uint32_t second = left_close ? right : left;
-    const bool c1 = (t_split > w.t_max || t_split <= 0);
+    const bool c1 = (t_split > w.t_max) | (t_split <= 0);
     const bool c2 = (t_split < w.t_min);
-    if (!c1 && !c2) {
+    const bool push = !c1 & !c2;
+    if (push) {
         const uint2 e = make_uint2(second, __float_as_uint(t_split));
         if (w.sp < (uint32_t)LDS_DEPTH) col[w.sp * 64] = e;
         else if (w.sp < RT_MAX_STACK) spill[w.sp - LDS_DEPTH] = e;
-        w.sp++;
-        w.t_max = t_split;
     }
-    walk_enter(w, (c1 || !c2) ? first : second);
+    w.sp += push ? 1u : 0u;
+    w.t_max = push ? t_split : w.t_max;
+    walk_enter(w, (c1 | !c2) ? first : second);
 }
 
 // The lane stands on an interior node: fetch its two-level record (32 bytes,
@@ -258,43 +260,47 @@ template <int LDS_DEPTH>
 __device__ __forceinline__ bool walk_leaf(const TravScene &P, Walk &w, f3 o, f3 d, const float4 &T0, const float4 &T1,
                                           const float4 &T2, uint2 *__restrict__ col, uint2 *__restrict__ spill)
 {
-    bool finished = false;
-    if (w.li < w.lc) {
-        if (w.li == 0 && w.lc == 31u) w.lc = __float_as_uint(T1.w);
-        float t, u, v;
-        if (tri_hit_edges(xyz(T0), xyz(T1), xyz(T2), o, d, t, u, v)) {
-            if (!(t <= 0) && t < w.t_hit) {
-                w.t_hit = t; w.hu = u; w.hv = v; w.tri_indx = __float_as_uint(T0.w);
-                if (w.t_hit < w.t_max) finished = true;
-            }
-        }
-        w.li++;
-    }
-    if (!finished && w.li >= w.lc) {
-        // leaf used up: the reference's outer loop test, then restart or pop
-        if ((P.root_ref & RT_REF_LEAF) || !(w.t_max < w.scene_t_max)) finished = true;
-        else if (w.sp == 0) {
-            w.t_min = w.t_max; w.t_max = w.scene_t_max;
-            walk_enter(w, P.root_ref);
+    // the triangle, for lanes that have one left (the others hold zeros in T0..T2: no hit)
+    const bool has = w.li < w.lc;
+    w.lc = (has & (w.li == 0) & (w.lc == 31u)) ? __float_as_uint(T1.w) : w.lc;
+    float t, u, v;
+    const bool hit = tri_hit_edges(xyz(T0), xyz(T1), xyz(T2), o, d, t, u, v);
+    const bool take = has & hit & !(t <= 0) & (t < w.t_hit);
+    w.t_hit = take ? t : w.t_hit;
+    w.hu = take ? u : w.hu;
+    w.hv = take ? v : w.hv;
+    w.tri_indx = take ? __float_as_uint(T0.w) : w.tri_indx;
+    bool finished = take & (t < w.t_max);
+    w.li += has ? 1u : 0u;
+
+    // leaf used up: the reference's outer loop test, then restart or pop.  Entry
+    // sp-1 is popped; the t_max that goes with it is the t_split of entry sp-2
+    // (scene_t_max at the bottom).  A restart is a pop of {root, t_max} with
+    // scene_t_max below it.
+    const bool used_up = !finished & (w.li >= w.lc);
+    const bool ends = used_up & (((P.root_ref & RT_REF_LEAF) != 0u) | !(w.t_max < w.scene_t_max));
+    const bool next = used_up & !ends;
+    const bool pop = next & (w.sp != 0u);
+    uint2 e = make_uint2(P.root_ref, __float_as_uint(w.t_max));
+    uint32_t below = __float_as_uint(w.scene_t_max);
+    if (pop) {
+        const uint32_t s = w.sp - 1u;
+        if (s < (uint32_t)LDS_DEPTH) {
+            e = col[s * 64];
+            const uint32_t under = col[(s > 0u ? s - 1u : 0u) * 64].y;
+            below = s > 0u ? under : below;
         } else {
-            // entry sp-1 is popped; the t_max that goes with it is the t_split of
-            // entry sp-2 (scene_t_max at the bottom).  LDS and spill levels are
-            // read on separate paths so each stays a plain ds_read / scratch_load.
-            w.sp--;
-            uint2 e, below = make_uint2(0u, __float_as_uint(w.scene_t_max));
-            if (w.sp < (uint32_t)LDS_DEPTH) {
-                e = col[w.sp * 64];
-                if (w.sp > 0) below = col[(w.sp - 1) * 64];
-            } else {
-                e = spill[w.sp - LDS_DEPTH];
-                below = (w.sp - 1 < (uint32_t)LDS_DEPTH) ? col[(LDS_DEPTH - 1) * 64] : spill[w.sp - 1 - LDS_DEPTH];
-            }
-            w.t_min = __uint_as_float(e.y);
-            w.t_max = __uint_as_float(below.y);
-            walk_enter(w, e.x);
+            e = spill[s - LDS_DEPTH];
+            below = (s - 1u < (uint32_t)LDS_DEPTH) ? col[(LDS_DEPTH - 1) * 64].y : spill[s - 1u - LDS_DEPTH].y;
         }
     }
-    return finished;
+    w.sp -= pop ? 1u : 0u;
+    if (next) {
+        w.t_min = __uint_as_float(e.y);
+        w.t_max = __uint_as_float(below);
+        walk_enter(w, e.x);
+    }
+    return finished | ends;
 }
 
 // walk_leaf for callers that have not fetched the triangle: loads it only when
