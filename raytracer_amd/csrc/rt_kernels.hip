@@ -168,14 +168,14 @@ struct TravScene {
 struct Walk {
     float t_min, t_max, scene_t_max, t_hit, hu, hv;
     uint32_t tri_indx, sp;
-    uint32_t ref;            // where the lane stands: interior index or leaf descriptor
-    uint32_t li, lc, slot;   // leaf progress: triangle li of lc, first slot
+    uint32_t ref;            // where the lane stands: interior reference or leaf descriptor
+    uint32_t li, lc;         // leaf progress: triangle li of lc (lc is settled at the leaf's first step)
 };
 
 __device__ __forceinline__ void walk_enter(Walk &w, uint32_t ref)
 {
     w.ref = ref;
-    w.lc = RT_REF_COUNT(ref); w.slot = ref & RT_REF_SLOT_MASK; w.li = 0;   // meaningful when ref is a leaf
+    w.li = 0;
 }
 
 // Start the walk of ray (o, d): slab clip against the scene box
@@ -201,12 +201,26 @@ __device__ __forceinline__ bool walk_begin(const TravScene &P, Walk &w, f3 o, f3
     return true;
 }
 
+// A register with no defined contents and no instruction spent on it: the
+// value of a load that only some lanes perform, for the lanes that do not.
+__device__ __forceinline__ void undefined_words(uint4 &x)
+{
+    asm volatile("" : "=v"(x.x), "=v"(x.y), "=v"(x.z), "=v"(x.w));
+}
+
+// The walk steps below are written for a wave whose lanes are in different
+// states: every lane runs the same straight instruction stream and `en` (or
+// `in_leaf`) says whether the step is the lane's to take; state changes are
+// selects, only loads and stack stores sit in branches.  Wrapping a step in
+// "if (en)" instead costs a register copy per state word and nesting level on
+// every trip of the kernels' loops.
+
 // One descend step at an interior node with split plane (k, b) and children
 // (left, right), reference: src/kernels/kdtree.cl:229-260.  get_elem (:67-75)
 // adds the masked-out zeros, which turns -0 into +0.
 template <int LDS_DEPTH>
 __device__ __forceinline__ void walk_descend(Walk &w, f3 o, f3 d, uint32_t k, float b, uint32_t left, uint32_t right,
-                                             uint2 *__restrict__ col, uint2 *__restrict__ spill)
+                                             uint2 *__restrict__ col, uint2 *__restrict__ spill, bool en)
 {
     const float ok = ((k == 0) ? o.x : ((k == 1) ? o.y : o.z)) + 0.0f;
     const float dk = ((k == 0) ? d.x : ((k == 1) ? d.y : d.z)) + 0.0f;
@@ -216,7 +230,7 @@ __device__ __forceinline__ void walk_descend(Walk &w, f3 o, f3 d, uint32_t k, fl
     const uint32_t second = left_close ? right : left;
     const bool c1 = (t_split > w.t_max) | (t_split <= 0);
     const bool c2 = (t_split < w.t_min);
-    const bool push = !c1 & !c2;
+    const bool push = en & !c1 & !c2;
     if (push) {
         const uint2 e = make_uint2(second, __float_as_uint(t_split));
         if (w.sp < (uint32_t)LDS_DEPTH) col[w.sp * 64] = e;
@@ -224,45 +238,51 @@ __device__ __forceinline__ void walk_descend(Walk &w, f3 o, f3 d, uint32_t k, fl
     }
     w.sp += push ? 1u : 0u;
     w.t_max = push ? t_split : w.t_max;
-    walk_enter(w, (c1 | !c2) ? first : second);
+    const uint32_t to = (c1 | !c2) ? first : second;
+    w.ref = en ? to : w.ref;
+    w.li = en ? 0u : w.li;
 }
 
-// The lane stands on an interior node: fetch its two-level record (32 bytes,
-// layout in rt_hip.h) and descend -- from the record's top through one of its
-// children when that child is interior too, so up to two levels per fetch; a
-// lane that arrives at a child position (popped from the stack) takes one.
+// Lanes with `en` stand on an interior node: fetch its two-level record (32
+// bytes, layout in rt_hip.h) and descend -- from the record's top through one
+// of its children when that child is interior too, so up to two levels per
+// fetch; a lane that arrives at a child position (popped from the stack) takes
+// one.
 template <int LDS_DEPTH>
 __device__ __forceinline__ void walk_interior(const TravScene &P, Walk &w, f3 o, f3 d, uint2 *__restrict__ col,
-                                              uint2 *__restrict__ spill)
+                                              uint2 *__restrict__ spill, bool en)
 {
     const uint32_t top = w.ref & ~3u;                    // reference of the record's top = record index * 4
-    const uint4 *rec = (const uint4 *)((const char *)P.nodes + (top << 3));
-    uint4 a = rec[0], r = rec[1];
+    uint4 a, r;
+    undefined_words(a); undefined_words(r);
+    if (en) {
+        const uint4 *rec = (const uint4 *)((const char *)P.nodes + (top << 3));
+        a = rec[0]; r = rec[1];
+    }
     // both halves are fetched here, together: left alone, the compiler sinks the
-    // words only the first step needs into that branch, as a second round trip
+    // words only the first step needs into that step, as a second round trip
     asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(r.x), "+v"(r.y), "+v"(r.z), "+v"(r.w));
     const uint32_t packed = a.w;
-    if ((w.ref & 3u) == 0u) {
-        const uint32_t left = (packed & 64u) ? r.x : (top | 1u);
-        const uint32_t right = (packed & 128u) ? r.z : (top | 2u);
-        walk_descend<LDS_DEPTH>(w, o, d, packed & 3u, __uint_as_float(a.x), left, right, col, spill);
-        if ((w.ref & RT_REF_LEAF) || (w.ref & 3u) == 0u) return;     // at a leaf (cannot be another record's top here)
-    }
+    const bool en1 = en & ((w.ref & 3u) == 0u);
+    const uint32_t left = (packed & 64u) ? r.x : (top | 1u);
+    const uint32_t right = (packed & 128u) ? r.z : (top | 2u);
+    walk_descend<LDS_DEPTH>(w, o, d, packed & 3u, __uint_as_float(a.x), left, right, col, spill, en1);
+    // now at a leaf or at a child position of this record (never at another record's top)
+    const bool en2 = en & !(w.ref & RT_REF_LEAF) & ((w.ref & 3u) != 0u);
     const bool at_left = (w.ref & 3u) == 1u;
     walk_descend<LDS_DEPTH>(w, o, d, (packed >> (at_left ? 2 : 4)) & 3u, __uint_as_float(at_left ? a.y : a.z),
-                            at_left ? r.x : r.z, at_left ? r.y : r.w, col, spill);
+                            at_left ? r.x : r.z, at_left ? r.y : r.w, col, spill, en2);
 }
 
-// One step of a lane standing in a leaf (src/kernels/kdtree.cl:263-302): test
-// the next triangle, and when the leaf is used up pop / restart / end.  true
-// when the walk has ended (w.t_hit etc. hold the result, +inf for a miss).
+// One step of the lanes standing in a leaf (`in_leaf`), src/kernels/kdtree.cl:263-302:
+// test the next triangle, and when the leaf is used up pop / restart / end.
+// `has` says which of them have a triangle left, T0..T2 hold it.  true when the
+// lane's walk has ended (w.t_hit etc. hold the result, +inf for a miss).
 template <int LDS_DEPTH>
 __device__ __forceinline__ bool walk_leaf(const TravScene &P, Walk &w, f3 o, f3 d, const float4 &T0, const float4 &T1,
-                                          const float4 &T2, uint2 *__restrict__ col, uint2 *__restrict__ spill)
+                                          const float4 &T2, uint2 *__restrict__ col, uint2 *__restrict__ spill,
+                                          bool in_leaf, bool has)
 {
-    // the triangle, for lanes that have one left (the others hold zeros in T0..T2: no hit)
-    const bool has = w.li < w.lc;
-    w.lc = (has & (w.li == 0) & (w.lc == 31u)) ? __float_as_uint(T1.w) : w.lc;
     float t, u, v;
     const bool hit = tri_hit_edges(xyz(T0), xyz(T1), xyz(T2), o, d, t, u, v);
     const bool take = has & hit & !(t <= 0) & (t < w.t_hit);
@@ -270,14 +290,14 @@ __device__ __forceinline__ bool walk_leaf(const TravScene &P, Walk &w, f3 o, f3 
     w.hu = take ? u : w.hu;
     w.hv = take ? v : w.hv;
     w.tri_indx = take ? __float_as_uint(T0.w) : w.tri_indx;
-    bool finished = take & (t < w.t_max);
+    const bool finished = take & (t < w.t_max);
     w.li += has ? 1u : 0u;
 
     // leaf used up: the reference's outer loop test, then restart or pop.  Entry
     // sp-1 is popped; the t_max that goes with it is the t_split of entry sp-2
     // (scene_t_max at the bottom).  A restart is a pop of {root, t_max} with
     // scene_t_max below it.
-    const bool used_up = !finished & (w.li >= w.lc);
+    const bool used_up = in_leaf & !finished & (w.li >= w.lc);
     const bool ends = used_up & (((P.root_ref & RT_REF_LEAF) != 0u) | !(w.t_max < w.scene_t_max));
     const bool next = used_up & !ends;
     const bool pop = next & (w.sp != 0u);
@@ -295,26 +315,36 @@ __device__ __forceinline__ bool walk_leaf(const TravScene &P, Walk &w, f3 o, f3 
         }
     }
     w.sp -= pop ? 1u : 0u;
-    if (next) {
-        w.t_min = __uint_as_float(e.y);
-        w.t_max = __uint_as_float(below);
-        walk_enter(w, e.x);
-    }
+    w.t_min = next ? __uint_as_float(e.y) : w.t_min;
+    w.t_max = next ? __uint_as_float(below) : w.t_max;
+    w.ref = next ? e.x : w.ref;
+    w.li = next ? 0u : w.li;
     return finished | ends;
 }
 
-// walk_leaf for callers that have not fetched the triangle: loads it only when
-// there is one to test.
+// walk_leaf with the triangle fetch: lanes that have a triangle left load it
+// (48 bytes), the others pay for no cache lookup.  The triangle count of the
+// leaf is settled at its first step: the descriptor's, or for a long leaf the
+// one stored with the first triangle.
 template <int LDS_DEPTH>
 __device__ __forceinline__ bool walk_leaf_load(const TravScene &P, Walk &w, f3 o, f3 d, uint2 *__restrict__ col,
-                                               uint2 *__restrict__ spill)
+                                               uint2 *__restrict__ spill, bool in_leaf)
 {
-    float4 T0 = make_float4(0, 0, 0, 0), T1 = T0, T2 = T0;
-    if (w.li < w.lc) {
-        const float4 *tp = (const float4 *)((const char *)P.leaf_tris + (w.slot + w.li) * 48u);
-        T0 = tp[0]; T1 = tp[1]; T2 = tp[2];
+    const bool first = w.li == 0u;
+    const uint32_t count = RT_REF_COUNT(w.ref);
+    w.lc = first ? count : w.lc;
+    const bool has = in_leaf & (w.li < w.lc);
+    uint4 t0, t1, t2;
+    undefined_words(t0); undefined_words(t1); undefined_words(t2);
+    if (has) {
+        const uint4 *tp = (const uint4 *)((const char *)P.leaf_tris + ((w.ref & RT_REF_SLOT_MASK) + w.li) * 48u);
+        t0 = tp[0]; t1 = tp[1]; t2 = tp[2];
     }
-    return walk_leaf<LDS_DEPTH>(P, w, o, d, T0, T1, T2, col, spill);
+    w.lc = (first & (count == 31u)) ? t1.w : w.lc;
+    const float4 T0 = make_float4(__uint_as_float(t0.x), __uint_as_float(t0.y), __uint_as_float(t0.z), __uint_as_float(t0.w));
+    const float4 T1 = make_float4(__uint_as_float(t1.x), __uint_as_float(t1.y), __uint_as_float(t1.z), __uint_as_float(t1.w));
+    const float4 T2 = make_float4(__uint_as_float(t2.x), __uint_as_float(t2.y), __uint_as_float(t2.z), __uint_as_float(t2.w));
+    return walk_leaf<LDS_DEPTH>(P, w, o, d, T0, T1, T2, col, spill, in_leaf, has);
 }
 
 __device__ __forceinline__ Hit walk_result(const Walk &w)
@@ -389,9 +419,11 @@ __global__ __launch_bounds__(64) void k_kd_intersect(TravScene P, const float4 *
         }
         // one record (up to two descend steps) for the lanes on interior nodes,
         // then one triangle for the lanes in leaves
-        if (walking && !(w.ref & RT_REF_LEAF)) walk_interior<LDS_DEPTH>(P, w, o, d, col, spill);
-        if (walking && (w.ref & RT_REF_LEAF)) {
-            if (walk_leaf_load<LDS_DEPTH>(P, w, o, d, col, spill)) {
+        const bool in_node = walking & !(w.ref & RT_REF_LEAF);
+        if (__any(in_node)) walk_interior<LDS_DEPTH>(P, w, o, d, col, spill, in_node);
+        const bool in_leaf = walking & ((w.ref & RT_REF_LEAF) != 0u);
+        if (__any(in_leaf)) {
+            if (walk_leaf_load<LDS_DEPTH>(P, w, o, d, col, spill, in_leaf)) {
                 hits[ridx] = walk_result(w);
                 walking = false;
             }
@@ -627,6 +659,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
     __shared__ uint2 stack[LDS_DEPTH * 64];
     uint2 spill[RT_MAX_STACK - LDS_DEPTH];
     uint2 *const col = stack + threadIdx.x;
+    // With several slots of a kind per trip some find no lane to serve: those
+    // are jumped over.  With one slot of each kind that hardly happens, and the
+    // jump would cost a register copy per state word on every trip.
+    constexpr bool SKIP_EMPTY = (NI + NT) > 2;
 
     enum { FREE = 0, WALK = 1, DONE = 2 };
     WorkQueue q;
@@ -701,16 +737,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         // same trip
 #pragma unroll
         for (int r = 0; r < NI; r++) {
-            if (mode == WALK && !(w.ref & RT_REF_LEAF)) {
-                steps++;
-                walk_interior<LDS_DEPTH>(P, w, o, d, col, spill);
+            const bool in_node = (mode == WALK) & !(w.ref & RT_REF_LEAF);
+            if (!SKIP_EMPTY || __any(in_node)) {
+                steps += in_node ? 1u : 0u;
+                walk_interior<LDS_DEPTH>(P, w, o, d, col, spill, in_node);
             }
         }
 #pragma unroll
         for (int r = 0; r < NT; r++) {
-            if (mode == WALK && (w.ref & RT_REF_LEAF)) {
-                steps++;
-                if (walk_leaf_load<LDS_DEPTH>(P, w, o, d, col, spill)) mode = DONE;
+            const bool in_leaf = (mode == WALK) & ((w.ref & RT_REF_LEAF) != 0u);
+            if (!SKIP_EMPTY || __any(in_leaf)) {
+                steps += in_leaf ? 1u : 0u;
+                const bool fin = walk_leaf_load<LDS_DEPTH>(P, w, o, d, col, spill, in_leaf);
+                mode = fin ? (uint32_t)DONE : mode;
             }
         }
     }
@@ -1194,6 +1233,11 @@ void launch_spath_run(rt_device *dev, const TravScene &P, const SpathDev &B, uin
     case 8: launch_run_variant<12, 16, 64, 1, 2, 6>(dev, P, B, n, iters, rv); break;
     case 9: launch_run_variant<12, 16, 64, 1, 2, 5>(dev, P, B, n, iters, rv); break;   // = RT_SCHEDULE_TWO_LEAF_SLOTS
     case 10: launch_run_variant<12, 16, 64, 2, 2, 5>(dev, P, B, n, iters, rv); break;
+    case 11: launch_run_variant<10, 16, 64, 1, 1, 8>(dev, P, B, n, iters, rv); break;
+    case 12: launch_run_variant<8, 16, 64, 1, 1, 8>(dev, P, B, n, iters, rv); break;
+    case 13: launch_run_variant<10, 16, 64, 1, 1, 6>(dev, P, B, n, iters, rv); break;
+    case 14: launch_run_variant<10, 16, 64, 1, 2, 7>(dev, P, B, n, iters, rv); break;
+    case 15: launch_run_variant<10, 16, 64, 2, 2, 7>(dev, P, B, n, iters, rv); break;
     default: launch_run_variant<10, 16, 64, 1, 1, 7>(dev, P, B, n, iters, rv); break;
     }
 }
