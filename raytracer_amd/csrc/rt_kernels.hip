@@ -1238,6 +1238,7 @@ void launch_spath_run(rt_device *dev, const TravScene &P, const SpathDev &B, uin
     case 13: launch_run_variant<10, 16, 64, 1, 1, 6>(dev, P, B, n, iters, rv); break;
     case 14: launch_run_variant<10, 16, 64, 1, 2, 7>(dev, P, B, n, iters, rv); break;
     case 15: launch_run_variant<10, 16, 64, 2, 2, 7>(dev, P, B, n, iters, rv); break;
+    case 16: launch_run_variant<11, 16, 64, 1, 1, 7>(dev, P, B, n, iters, rv); break;
     default: launch_run_variant<10, 16, 64, 1, 1, 7>(dev, P, B, n, iters, rv); break;
     }
 }
