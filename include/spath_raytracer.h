@@ -60,7 +60,8 @@ typedef struct spath_raytracer_context {
     int          no_reorder;             /* 1: always serve pixels in index order */
     int          schedule;               /* RT_SCHEDULE_* the batches run with */
     int          schedule_fixed;         /* 1: keep `schedule`; 0: the first batch of a render that is long enough is
-                                            split in two launches, one per schedule, and the faster one is kept */
+                                            split in three launches (default, alternative, default schedule), and the
+                                            alternative is kept if it beats both default runs by 5 % */
     int          trial_state;            /* 0: not tried yet, 1: trial queued, 2: decided */
     rt_event     trial_marks[4];
     unsigned int trial_iters[3];

@@ -1,7 +1,8 @@
 #!/bin/bash
 # Counter passes for the benchmark's dominant kernel.  One rocprofv3 run per
 # pass (counters of one block per run stay within the hardware's slots).
-# usage: profiles/pmc_passes.sh <workload> <outdir>
+# usage: [STEPS=.. WARMUP=.. BENCH_ARGS="--schedule 0"] profiles/pmc_passes.sh <workload> <outdir>
+# (--schedule 0 keeps the warm-up batch one launch instead of the three timed parts of the schedule trial)
 set -u
 WL=${1:-c3}
 OUT=${2:-gpurun_out/pmc_$WL}
@@ -10,7 +11,7 @@ mkdir -p "$OUT"
 run() {
     name=$1; shift
     timeout -s KILL 180 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -o "$name" -- \
-        python3 bench.py --workload "$WL" --steps ${STEPS:-6} --warmup ${WARMUP:-2} --no-cpu-baseline > "$OUT/$name.log" 2>&1 || return 1
+        python3 bench.py --workload "$WL" --steps ${STEPS:-6} --warmup ${WARMUP:-2} --no-cpu-baseline ${BENCH_ARGS:-} > "$OUT/$name.log" 2>&1 || return 1
 }
 run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD || exit 1
 run sq2 SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_SALU SQ_INSTS_VMEM_WR SQ_INST_LEVEL_VMEM SQ_ACTIVE_INST_LDS || exit 1
