@@ -20,7 +20,8 @@ import numpy as np
 from . import scenes  # noqa: F401  (re-exported)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libraytracer_amd.so")
+# RT_LIB_PATH: another build of the library (A/B timing of two builds in one session)
+LIB_PATH = os.environ.get("RT_LIB_PATH") or os.path.join(_HERE, "libraytracer_amd.so")
 
 SS_RAYTRACER, PATH_RAYTRACER, SPLIT_PATH_RAYTRACER = 0, 1, 2
 RT_RNG_LIBC, RT_RNG_SPLITMIX = 0, 1

@@ -137,12 +137,15 @@ def test_interleaved_bands_equal_full_frame(rt, orc, small):
     assert sorted(seen) == list(range(h))
 
 
-def test_batches_and_heaviest_first_order_do_not_change_results(rt, orc, small):
+@pytest.mark.parametrize("size", [(256, 256), (300, 250)])
+def test_batches_and_heaviest_first_order_do_not_change_results(rt, orc, small, size):
     """A frame large enough for the cost-ordered scheduling (>= 65,536 pixels),
     rendered in three batches (2 + 2 + 1 iterations; the 2nd and 3rd are served
-    heaviest pixel first), equals the oracle's iteration-by-iteration result."""
+    heaviest first), equals the oracle's iteration-by-iteration result.  256x256
+    divides into 8x8 screen tiles and is ordered tile by tile; 300x250 does not
+    and is ordered pixel by pixel."""
     sc, tree = small
-    w, h, iters, seed = 256, 256, 5, 13
+    (w, h), iters, seed = size, 5, 13
     r = rt.Renderer(sc, w, h).build()
     r.init_spath(seed=seed, resolve_interval=0, max_batch=2)
     r.spath_prepass(num_iterations=iters)
@@ -150,6 +153,7 @@ def test_batches_and_heaviest_first_order_do_not_change_results(rt, orc, small):
     g = r.spath_state()
     order = r.download(r.spath.contents.cl_pixel_order_buffer, np.uint32, w * h)
     cost = r.download(r.spath.contents.cl_pixel_cost_buffer, np.uint32, w * h)
+    tiled = bool(r.spath.contents.cl_tile_scratch_buffer)
     r.close()
     st = oracle_spath_run(orc, sc, tree, w, h, seed, iters)
     assert_bits_equal(g["out_tex"], st.out_tex, "out_tex")
@@ -160,6 +164,15 @@ def test_batches_and_heaviest_first_order_do_not_change_results(rt, orc, small):
     # the order buffer is a permutation, heaviest bucket first
     assert np.array_equal(np.sort(order), np.arange(w * h, dtype=np.uint32))
     assert cost.max() > 0
+    assert tiled == (w % 8 == 0 and h % 8 == 0)
+    if tiled:
+        # every run of 64 work items is one 8x8 tile, and the tiles come by decreasing cost bucket of their mean
+        x, y = (order % w).reshape(-1, 64), (order // w).reshape(-1, 64)
+        assert ((x.max(1) - x.min(1)) == 7).all() and ((y.max(1) - y.min(1)) == 7).all()
+        assert (x.min(1) % 8 == 0).all() and (y.min(1) % 8 == 0).all()
+        mean = cost[order].reshape(-1, 64).sum(1) >> 6
+        bucket = np.minimum(mean >> 1, 255)          # the last batch had one iteration: buckets of two steps
+        assert (np.diff(bucket.astype(np.int64)) <= 0).all()
 
 
 def test_deep_stack_scene_bit_exact(rt, orc):
