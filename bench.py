@@ -117,8 +117,8 @@ def main():
     ap.add_argument("--separate-kernels", action="store_true", help="three launches per iteration, as the reference")
     ap.add_argument("--max-batch", type=int, default=None, help="most iterations folded into one launch")
     ap.add_argument("--no-reorder", action="store_true", help="serve pixels in index order in every batch")
-    ap.add_argument("--schedule", type=int, default=None, choices=[0, 1],
-                    help="fix the kernel's slot schedule (default: the library times both on its first batch)")
+    ap.add_argument("--schedule", type=int, default=None, choices=[0, 1, 2],
+                    help="fix the kernel's slot schedule (default: the library times them on its first batch)")
     ap.add_argument("--size", type=int, default=0, help="override the workload's frame: SIZE x SIZE pixels (tuning runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)

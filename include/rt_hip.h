@@ -195,6 +195,10 @@ void rt_k_xorshift(rt_device *dev, rt_mem random, uint32_t n);
    kernel's loop (RT_SCHEDULE_*): also scheduling only. */
 #define RT_SCHEDULE_ONE_LEAF_SLOT  0   /* scenes whose rays test about as many triangles as they fetch node records */
 #define RT_SCHEDULE_TWO_LEAF_SLOTS 1   /* triangle-heavy walks (unstructured soups, long leaves) */
+#define RT_SCHEDULE_SHORT_CHAINS   2   /* two descend and two leaf slots per trip, 16 stack levels in LDS: when the frame
+                                          (or a rank's share of it) has too few pixels to keep every lane busy, a batch
+                                          lasts as long as its heaviest pixel's chain of steps, and this shortens it */
+#define RT_SCHEDULE_COUNT          3
 void rt_k_spath_run(rt_device *dev, const rt_kd_view *kd, const rt_spath_buffers *b, uint32_t n, uint32_t iters,
                     rt_mem random_values, rt_mem cost, rt_mem order, int schedule);
 

@@ -18,6 +18,8 @@ enum {
                              value of launch k = splitmix32(rng_seed + 1, k); reproducible */
 };
 
+#define RT_TRIAL_PARTS 4   /* launches of a schedule trial: default, two alternatives, default */
+
 typedef struct spath_raytracer_context {
     struct _rt_ctx *rctx;
     bool up_to_date;
@@ -60,11 +62,12 @@ typedef struct spath_raytracer_context {
     int          no_reorder;             /* 1: always serve pixels in index order */
     int          schedule;               /* RT_SCHEDULE_* the batches run with */
     int          schedule_fixed;         /* 1: keep `schedule`; 0: the first batch of a render that is long enough is
-                                            split in three launches (default, alternative, default schedule), and the
-                                            alternative is kept if it beats both default runs by 5 % */
+                                            split in RT_TRIAL_PARTS launches (default schedule, the alternatives,
+                                            default again), and an alternative is kept if it beats both default runs
+                                            by 5 % */
     int          trial_state;            /* 0: not tried yet, 1: trial queued, 2: decided */
-    rt_event     trial_marks[4];
-    unsigned int trial_iters[3];
+    rt_event     trial_marks[RT_TRIAL_PARTS + 1];
+    unsigned int trial_iters[RT_TRIAL_PARTS];
 } spath_raytracer_context;
 
 spath_raytracer_context *init_spath_raytracer_context(struct _rt_ctx *rctx);   /* src/spath_raytracer.c:39-116 */

@@ -140,7 +140,7 @@ class spath_raytracer_context(C.Structure):
                 ("cl_cost_hist_buffer", C.c_void_p), ("cl_tile_scratch_buffer", C.c_void_p),
                 ("order_valid", C.c_bool), ("no_reorder", C.c_int),
                 ("schedule", C.c_int), ("schedule_fixed", C.c_int), ("trial_state", C.c_int),
-                ("trial_marks", C.c_void_p * 4), ("trial_iters", C.c_uint * 3)]
+                ("trial_marks", C.c_void_p * 5), ("trial_iters", C.c_uint * 4)]
 
 
 class rt_device_props(C.Structure):

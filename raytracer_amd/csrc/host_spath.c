@@ -109,23 +109,31 @@ static void upload_random_buffer(spath_raytracer_context *c)
     rt_mem_upload(rctx->rcl->device, c->cl_random_buffer, c->random_buffer, n * sizeof(unsigned int));
 }
 
-/* Reads the timings of a queued schedule trial (waits for the launches) and keeps the faster schedule.  The
-   trial ran default / alternative / default; the alternative has to beat the better of the two default runs by
-   5 % to displace it, so a slow first launch (cold caches, clocks still ramping) cannot decide it. */
+/* The parts of a schedule trial: the default schedule first and last, the alternatives between. */
+static const int trial_schedule[RT_TRIAL_PARTS] = { RT_SCHEDULE_ONE_LEAF_SLOT, RT_SCHEDULE_TWO_LEAF_SLOTS,
+                                                    RT_SCHEDULE_SHORT_CHAINS, RT_SCHEDULE_ONE_LEAF_SLOT };
+static const char *schedule_name[RT_SCHEDULE_COUNT] = { "one leaf slot", "two leaf slots", "short chains" };
+
+/* Reads the timings of a queued schedule trial (waits for the launches) and keeps the fastest schedule.  An
+   alternative has to beat the better of the two default runs by 5 % to displace the default, so a slow first
+   launch (cold caches, clocks still ramping) cannot decide it. */
 static void finish_schedule_trial(spath_raytracer_context *c)
 {
     if (c->trial_state != 1) return;
     rt_device *dev = c->rctx->rcl->device;
-    float t[3];
-    for (int k = 0; k < 3; k++)
+    float t[RT_TRIAL_PARTS];
+    for (int k = 0; k < RT_TRIAL_PARTS; k++)
         t[k] = rt_event_elapsed_ms(dev, c->trial_marks[k], c->trial_marks[k + 1]) / (float)c->trial_iters[k];
-    const float a = t[0] < t[2] ? t[0] : t[2];
-    c->schedule = (t[1] < 0.95f * a) ? RT_SCHEDULE_TWO_LEAF_SLOTS : RT_SCHEDULE_ONE_LEAF_SLOT;
-    for (int k = 0; k < 4; k++) { rt_event_release(dev, c->trial_marks[k]); c->trial_marks[k] = NULL; }
+    float best = t[0] < t[RT_TRIAL_PARTS - 1] ? t[0] : t[RT_TRIAL_PARTS - 1];
+    best *= 0.95f;
+    c->schedule = RT_SCHEDULE_ONE_LEAF_SLOT;
+    for (int k = 1; k < RT_TRIAL_PARTS - 1; k++)
+        if (t[k] < best) { best = t[k]; c->schedule = trial_schedule[k]; }
+    for (int k = 0; k <= RT_TRIAL_PARTS; k++) { rt_event_release(dev, c->trial_marks[k]); c->trial_marks[k] = NULL; }
     c->trial_state = 2;
     if (!c->quiet)
-        printf("schedule trial: %.3f / %.3f / %.3f ms per iteration -> %s\n", t[0], t[1], t[2],
-               c->schedule == RT_SCHEDULE_TWO_LEAF_SLOTS ? "two leaf slots" : "one leaf slot");
+        printf("schedule trial: %.3f / %.3f / %.3f / %.3f ms per iteration -> %s\n", t[0], t[1], t[2], t[3],
+               schedule_name[c->schedule]);
 }
 
 /* Launches the iterations recorded since the last flush as one batch. */
@@ -150,18 +158,16 @@ void spath_raytracer_flush(spath_raytracer_context *c)
     finish_schedule_trial(c);
     const rt_mem order = (c->order_valid && !c->no_reorder) ? c->cl_pixel_order_buffer : NULL;
     unsigned int cost_iters = c->pending;      /* iterations the cost buffer will describe: those of the last launch */
-    if (!c->schedule_fixed && c->trial_state == 0 && c->pending >= 16 && n >= 65536) {
-        /* three parts of this batch, back to back in the same pixel order: default, alternative, default */
-        static const int part_schedule[3] = { RT_SCHEDULE_ONE_LEAF_SLOT, RT_SCHEDULE_TWO_LEAF_SLOTS,
-                                              RT_SCHEDULE_ONE_LEAF_SLOT };
+    if (!c->schedule_fixed && c->trial_state == 0 && c->pending >= 4 * RT_TRIAL_PARTS && n >= 65536) {
+        /* the parts of this batch run back to back in the same pixel order, one schedule each */
         unsigned int done = 0;
         c->trial_marks[0] = rt_event_record(dev);
-        for (int k = 0; k < 3; k++) {
-            const unsigned int part = (c->pending - done) / (unsigned int)(3 - k);
+        for (int k = 0; k < RT_TRIAL_PARTS; k++) {
+            const unsigned int part = (c->pending - done) / (unsigned int)(RT_TRIAL_PARTS - k);
             c->trial_iters[k] = part;
             rt_k_spath_run(dev, &rctx->stat_scene->kdt->view, &b, n, part,
                            (char *)c->cl_random_value_buffer + sizeof(unsigned int) * done,
-                           c->cl_pixel_cost_buffer, order, part_schedule[k]);
+                           c->cl_pixel_cost_buffer, order, trial_schedule[k]);
             c->trial_marks[k + 1] = rt_event_record(dev);
             done += part;
             cost_iters = part;

@@ -1196,6 +1196,8 @@ void launch_run_variant(rt_device *dev, const TravScene &P, const SpathDev &B, u
     if (!blocks_per_cu) {
         RT_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kern, 64, 0));
         if (blocks_per_cu < 1) blocks_per_cu = 1;
+        const char *cap = getenv("RT_WAVES_PER_CU");      // tuning: fewer resident waves than would fit
+        if (cap && atoi(cap) > 0 && atoi(cap) < blocks_per_cu) blocks_per_cu = atoi(cap);
         if (getenv("RT_VERBOSE")) fprintf(stderr, "[rt] render kernel: %d waves per CU\n", blocks_per_cu);
     }
     unsigned grid = (unsigned)blocks_per_cu * (unsigned)dev->props.multiProcessorCount;
@@ -1222,6 +1224,10 @@ void launch_spath_run(rt_device *dev, const TravScene &P, const SpathDev &B, uin
         launch_run_variant<12, 16, 64, 1, 2, 5>(dev, P, B, n, iters, rv);
         return;
     }
+    if (variant == 0 && schedule == RT_SCHEDULE_SHORT_CHAINS) {
+        launch_run_variant<16, 16, 64, 2, 2, 5>(dev, P, B, n, iters, rv);
+        return;
+    }
     switch (variant) {
     case 1: launch_run_variant<10, 16, 64, 2, 1, 7>(dev, P, B, n, iters, rv); break;
     case 2: launch_run_variant<10, 8, 64, 1, 1, 7>(dev, P, B, n, iters, rv); break;
@@ -1239,6 +1245,8 @@ void launch_spath_run(rt_device *dev, const TravScene &P, const SpathDev &B, uin
     case 14: launch_run_variant<10, 16, 64, 1, 2, 7>(dev, P, B, n, iters, rv); break;
     case 15: launch_run_variant<10, 16, 64, 2, 2, 7>(dev, P, B, n, iters, rv); break;
     case 16: launch_run_variant<11, 16, 64, 1, 1, 7>(dev, P, B, n, iters, rv); break;
+    case 17: launch_run_variant<16, 16, 64, 2, 2, 5>(dev, P, B, n, iters, rv); break;   // = RT_SCHEDULE_SHORT_CHAINS
+    case 19: launch_run_variant<16, 16, 64, 1, 1, 5>(dev, P, B, n, iters, rv); break;
     default: launch_run_variant<10, 16, 64, 1, 1, 7>(dev, P, B, n, iters, rv); break;
     }
 }

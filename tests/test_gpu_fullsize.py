@@ -143,10 +143,10 @@ def test_config2_full_frame_both_launch_structures(rt):
 
 def test_config5_size_strip_against_oracle(rt, orc):
     """10 M-triangle soup, four rows through the middle of a 3840x2160 frame: tree flattening at that size
-    (11 M nodes, 30 M leaf slots), long leaves, the two-leaf-slot schedule, against the oracle."""
+    (11 M nodes, 30 M leaf slots), long leaves, every slot schedule, against the oracle."""
     sc = rt.scenes.soup_scene(10_000_000)
     w, full_h, y0, rows, iters = 3840, 2160, 1078, 4, 5
-    for schedule in (1, 0):
+    for schedule in (1, 0, 2):
         r = rt.Renderer(sc, w, rows, tile_y0=y0, full_height=full_h).build()
         r.init_spath(seed=8, resolve_interval=0, quiet=True, schedule=schedule)
         r.spath_prepass(num_iterations=1 << 30)

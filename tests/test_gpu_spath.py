@@ -175,14 +175,16 @@ def test_batches_and_heaviest_first_order_do_not_change_results(rt, orc, small, 
         assert (np.diff(bucket.astype(np.int64)) <= 0).all()
 
 
-def test_deep_stack_scene_bit_exact(rt, orc):
+@pytest.mark.parametrize("schedule", [0, 1, 2])
+def test_deep_stack_scene_bit_exact(rt, orc, schedule):
     """Rays through an 82k-triangle mesh need more stack levels than the LDS part
-    holds (the reference's own limit is 16): the spill path must agree too."""
+    holds (the reference's own limit is 16): the spill path must agree too, under
+    every slot schedule of the render kernel."""
     sc = rt.scenes.icosphere_scene(6)
     tree = orc.KdTree(sc.verts4, sc.idx4)
     w, h, iters, seed = 128, 96, 4, 21
     r = rt.Renderer(sc, w, h).build()
-    r.init_spath(seed=seed, resolve_interval=0)
+    r.init_spath(seed=seed, resolve_interval=0, schedule=schedule)
     r.spath_prepass(num_iterations=iters)
     r.spath_render(iters)
     g = r.spath_state()
