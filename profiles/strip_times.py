@@ -8,7 +8,7 @@ sc = rt.scenes.icosphere_scene(8)
 W = H = 2048
 for N in ((8,) if len(sys.argv) > 2 else (2, 4, 8)):
     rows = H // N
-    ts = []
+    ts, picked = [], []
     for k in range(N if len(sys.argv) <= 2 else 2):
         if BANDS:
             first, band, stride, rows = band_partition(H, N, k)
@@ -19,6 +19,7 @@ for N in ((8,) if len(sys.argv) > 2 else (2, 4, 8)):
         r.spath_prepass(num_iterations=1 << 30)
         r.spath_render(50); r.sync()
         t0 = time.perf_counter(); r.spath_render(100); r.sync(); ts.append(time.perf_counter() - t0)
+        picked.append(int(r.spath.contents.schedule))
         r.close()
     full = 100 * W * H / 1e6
-    print(N, [round(t * 1e3, 1) for t in ts], "max-based Mrays/s", round(full / max(ts)), "ideal(sum)", round(full / sum(ts) * N), flush=True)
+    print(N, [round(t * 1e3, 1) for t in ts], "max-based Mrays/s", round(full / max(ts)), "ideal(sum)", round(full / sum(ts) * N), "schedules", picked, flush=True)
