@@ -134,3 +134,17 @@ def test_golden_brute_force_integrators(rt, orc):
     got = orc.path_trace(sc, rays, 96, 64, (0, 0, 0), 1)
     # seeds go through the C library's sin() of huge arguments: allow the odd pixel to differ between libm builds
     assert (got.view(np.uint32) != g["first_sample"].view(np.uint32)).any(axis=1).mean() <= 0.005
+
+
+def test_primary_visibility_matches_the_reference_stored_render(rt, orc):
+    """The one output of the reference itself that this path can be held against: its stored 1920x1080 frame of
+    res/scenes/path_obj2.rsc (renders/3_custom_2046.PNG; fixture and what is taken from it:
+    tests/golden/make_ref_render_fixture.py).  Ray generation, scene assembly and first-hit traversal of the
+    oracle reproduce the frame's emitter silhouette (276,947 pixels) pixel for pixel and cover every pixel that
+    shows the objects' colour."""
+    from helpers import load_ref_render_fixture, check_against_stored_render, oracle_spath_run
+    sc, w, h, emitter, objects = load_ref_render_fixture(rt)
+    assert emitter.sum() == 276947
+    tree = orc.KdTree(sc.verts4, sc.idx4)
+    st = oracle_spath_run(orc, sc, tree, w, h, 1, 0)
+    check_against_stored_render(sc, st.source_results, emitter, objects)

@@ -351,3 +351,19 @@ def test_default_rng_mode_renders_the_same_picture(rt, tmp_path):
     assert not np.array_equal(a, b)                       # different random streams
     assert abs(a.mean() - b.mean()) < 0.05 * a.mean()     # same picture
     assert np.sqrt(np.mean((a - b) ** 2)) < 40            # per-pixel noise of 24 samples, not a different image
+
+
+def test_primary_visibility_matches_the_reference_stored_render(rt, orc):
+    """The library's prepass at 1920x1080 on the reference's path_obj2 scene against the frame of it that the
+    reference stores (emitter silhouette pixel for pixel, see tests/golden/make_ref_render_fixture.py), and bit
+    for bit against the oracle."""
+    from helpers import load_ref_render_fixture, check_against_stored_render
+    sc, w, h, emitter, objects = load_ref_render_fixture(rt)
+    r = rt.Renderer(sc, w, h).build()
+    r.init_spath(seed=1, resolve_interval=0)
+    r.spath_prepass(num_iterations=4)
+    g = r.spath_state()
+    r.close()
+    check_against_stored_render(sc, g["source_results"], emitter, objects)
+    st = oracle_spath_run(orc, sc, orc.KdTree(sc.verts4, sc.idx4), w, h, 1, 0)
+    hits_equal(g["source_results"], st.source_results, "primary hits")
