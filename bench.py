@@ -189,6 +189,17 @@ def main():
 
     r.spath_render(args.warmup)
     sync_all()
+    if torch is not None and args.schedule is None and not args.separate_kernels:
+        # Every rank timed the kernel's slot schedules on its own share during the warm-up; the shares are
+        # interleaved bands of one picture, so they should agree, and a rank that a noisy timing sent the other
+        # way would set the job's time.  All ranks take the choice most of them made (results do not depend on it).
+        r.L.spath_raytracer_flush(r.spath)          # reads the trial's timings if they are still pending
+        r.sync()
+        mine = torch.zeros(3, dtype=torch.int64, device=f"cuda:{local_rank}" if backend == "nccl" else "cpu")
+        mine[int(r.spath.contents.schedule)] = 1
+        dist.all_reduce(mine)
+        r.spath.contents.schedule = int(torch.argmax(mine).item())
+        r.spath.contents.schedule_fixed = 1
     r.timing(True)
     r.timing_reset()
 

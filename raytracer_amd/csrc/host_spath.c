@@ -139,6 +139,7 @@ static void finish_schedule_trial(spath_raytracer_context *c)
 /* Launches the iterations recorded since the last flush as one batch. */
 void spath_raytracer_flush(spath_raytracer_context *c)
 {
+    finish_schedule_trial(c);        /* also with nothing pending: a caller that wants the decision flushes */
     if (!c->pending) return;
     raytracer_context *rctx = c->rctx;
     rt_device *dev = rctx->rcl->device;
