@@ -24,7 +24,8 @@ HIT_DT = np.dtype([("tri", "<u4"), ("t", "<f4"), ("u", "<f4"), ("v", "<f4")])
 class KdStats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("nodes_visited", C.c_uint64), ("leaves_visited", C.c_uint64),
                 ("tri_refs", C.c_uint64), ("tri_tests", C.c_uint64), ("pushes", C.c_uint64),
-                ("rays_over_16", C.c_uint64), ("max_stack", C.c_uint32), ("pad", C.c_uint32)]
+                ("rays_over_16", C.c_uint64), ("max_stack", C.c_uint32), ("pad", C.c_uint32),
+                ("empty_leaves", C.c_uint64)]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_ if n != "pad"}

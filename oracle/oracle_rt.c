@@ -505,6 +505,7 @@ typedef struct {
     uint64_t rays_over_16;      /* rays whose stack exceeded the reference's STACK_SIZE */
     uint32_t max_stack;
     uint32_t pad;
+    uint64_t empty_leaves;      /* visited leaves that hold no triangle */
 } orc_kd_stats;
 
 #define ORC_STACK 128
@@ -559,7 +560,7 @@ static orc_hit kd_trace_one(const uint8_t *blob, const int32_t *idx4, const floa
         /* leaf (kdtree.cl:263-302) */
         uint32_t ntri; memcpy(&ntri, blob + cur * 8 + 4, 4);
         const uint32_t *offs = (const uint32_t *)(blob + (cur + 2) * 8);
-        if (st) { st->leaves_visited++; st->tri_refs += ntri; }
+        if (st) { st->leaves_visited++; st->tri_refs += ntri; st->empty_leaves += (ntri == 0); }
         for (uint32_t i = 0; i < ntri; i++) {
             uint32_t off = offs[i];
             v3 a = v3_ld(verts4 + 4 * (size_t)idx4[4 * (size_t)(off + 0)]);
@@ -616,7 +617,7 @@ ORC_API void orc_kd_intersect(const uint8_t *blob, const int32_t *idx4, const fl
             total.rays += loc.rays; total.nodes_visited += loc.nodes_visited;
             total.leaves_visited += loc.leaves_visited; total.tri_refs += loc.tri_refs;
             total.tri_tests += loc.tri_tests; total.pushes += loc.pushes;
-            total.rays_over_16 += loc.rays_over_16;
+            total.rays_over_16 += loc.rays_over_16; total.empty_leaves += loc.empty_leaves;
             if (loc.max_stack > total.max_stack) total.max_stack = loc.max_stack;
         }
     }
