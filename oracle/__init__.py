@@ -114,6 +114,12 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+def set_builtins(mode: str) -> None:
+    """'plain' (default): dot/cross/min/max as the header of oracle_rt.c defines them; 'rocm': as ROCm's OpenCL
+    library defines them on gfx950, for bit-for-bit comparisons with the reference's kernels run there."""
+    lib().orc_set_builtins(C.c_int({"plain": 0, "rocm": 1}[mode]))
+
+
 def max_threads() -> int:
     return int(lib().orc_max_threads())
 
@@ -175,6 +181,14 @@ class KdTree:
                                _p(self.scene_min), _p(self.scene_max), _p(out),
                                C.byref(st) if stats else None, C.c_int(nthreads or max_threads()))
         return (out, st.as_dict()) if stats else out
+
+    def ray_stack(self, rays: np.ndarray, nthreads: int = 0) -> np.ndarray:
+        """Deepest traversal stack each ray needs (the reference's own stack holds 16 entries)."""
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
+        depth = np.zeros(rays.shape[0], np.uint32)
+        lib().orc_kd_ray_stack(_p(self.blob), _p(self.idx4), _p(self.verts4), _p(rays), C.c_uint32(rays.shape[0]),
+                               _p(self.scene_min), _p(self.scene_max), _p(depth), C.c_int(nthreads or max_threads()))
+        return depth
 
     def ray_steps(self, rays: np.ndarray, nthreads: int = 0) -> np.ndarray:
         """[n, 2] array: interior nodes visited and triangles tested per ray."""

@@ -57,6 +57,7 @@
 #endif
 
 #define ORC_API __attribute__((visibility("default")))
+#define ORC_API_DECL __attribute__((visibility("default")))
 
 /* ------------------------------------------------------------------------- */
 /* small vector helpers                                                       */
@@ -69,13 +70,30 @@ static inline v3 v3_add(v3 a, v3 b) { return V3(a.x + b.x, a.y + b.y, a.z + b.z)
 static inline v3 v3_sub(v3 a, v3 b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); }
 static inline v3 v3_mul(v3 a, v3 b) { return V3(a.x * b.x, a.y * b.y, a.z * b.z); }
 static inline v3 v3_scale(v3 a, float s) { return V3(a.x * s, a.y * s, a.z * s); }
-static inline float v3_dot(v3 a, v3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+/* Which definition of the OpenCL built-ins dot / cross / min / max is in force.
+ * 0 (default): the plain one of the header comment.  1: the one ROCm's OpenCL
+ * library has on gfx950 (read off the code it links into the reference's
+ * kernels): dot = fma(a.z,b.z, fma(a.y,b.y, a.x*b.x)), cross.x =
+ * fma(a.y,b.z, -(b.y*a.z)) and so on, min/max = IEEE minNum/maxNum.  Mode 1
+ * exists so that the reference's kernels, compiled by ROCm's clang and run on
+ * the GPU (oracle/refcl.py), can be compared with this restatement bit for
+ * bit; nothing else differs between the modes. */
+static int g_builtins = 0;
+ORC_API_DECL void orc_set_builtins(int mode) { g_builtins = mode; }
+
+static inline float v3_dot(v3 a, v3 b)
+{
+    if (g_builtins == 1) return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x));
+    return (a.x * b.x + a.y * b.y) + a.z * b.z;
+}
 static inline v3 v3_cross(v3 a, v3 b)
 {
+    if (g_builtins == 1)
+        return V3(fmaf(a.y, b.z, -(b.y * a.z)), fmaf(a.z, b.x, -(b.z * a.x)), fmaf(a.x, b.y, -(b.x * a.y)));
     return V3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
-static inline float cl_min(float a, float b) { return b < a ? b : a; }
-static inline float cl_max(float a, float b) { return a < b ? b : a; }
+static inline float cl_min(float a, float b) { return g_builtins == 1 ? fminf(a, b) : (b < a ? b : a); }
+static inline float cl_max(float a, float b) { return g_builtins == 1 ? fmaxf(a, b) : (a < b ? b : a); }
 static inline v3 v3_normalize(v3 a)
 {
     float len = sqrtf(v3_dot(a, a));
@@ -622,6 +640,24 @@ ORC_API void orc_kd_intersect(const uint8_t *blob, const int32_t *idx4, const fl
         }
     }
     if (stats) *stats = total;
+}
+
+/* deepest traversal stack each ray needs (the reference's private stack holds 16 entries, kdtree.cl:78,120) */
+ORC_API void orc_kd_ray_stack(const uint8_t *blob, const int32_t *idx4, const float *verts4,
+                              const float *rays, uint32_t n, const float *smin3, const float *smax3,
+                              uint32_t *depth, int nthreads)
+{
+    v3 smin = v3_ld(smin3), smax = v3_ld(smax3);
+#ifdef _OPENMP
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for schedule(dynamic, 1024) num_threads(nthreads)
+#endif
+    for (int64_t i = 0; i < (int64_t)n; i++) {
+        orc_kd_stats st;
+        memset(&st, 0, sizeof st);
+        kd_trace_one(blob, idx4, verts4, rays + 8 * i, smin, smax, &st);
+        depth[i] = st.max_stack;
+    }
 }
 
 /* per-ray work profile: steps[2*i] = interior nodes visited, steps[2*i+1] = triangles tested */

@@ -1,0 +1,300 @@
+"""GPU parity against the reference's OWN kernels.
+
+oracle/build_ref_kernels.py compiles the reference's OpenCL C kernel files, unmodified, with ROCm's clang and
+ROCm's OpenCL built-in library into gfx950 code objects (oracle/_ref/, built where the reference checkout is
+mounted; the built files travel to the GPU box, the sources do not).  oracle/refcl.py launches them on the MI355X
+with the reference's own argument lists.  These tests tie the three statements of the path together:
+
+    reference kernels (flavour "strict": no contraction, correctly rounded / and sqrt)
+        == oracle with ROCm's definitions of dot / cross / min / max       bit for bit (traversal)
+    oracle with the plain definitions == the library                        bit for bit (the other GPU tests)
+
+so that the only thing between the reference's kernels and the library is the definition of four OpenCL
+built-ins, which the OpenCL specification leaves to the implementation.  Shading goes through more built-ins
+(normalize, sqrt, sin, cos): it is compared one kernel step at a time on identical inputs, within a few ulp, and
+end to end as radiance.
+
+The reference's traversal keeps a private stack of 16 entries without a bounds check (src/kernels/kdtree.cl:78,120):
+rays that would need more are never handed to its kernel here (checked per ray with the oracle first).
+"""
+import numpy as np
+import pytest
+
+from helpers import assert_bits_equal, hits_equal, oracle_spath_run
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def refcl():
+    from oracle import refcl as m
+    if not m.available("ico4", "strict"):
+        pytest.skip("oracle/_ref holds no compiled reference kernels (built only where /root/reference is mounted)")
+    return m
+
+
+_cache = {}
+
+
+def _scene(rt, orc, refcl, tag, flavour):
+    key = (tag, flavour)
+    if key not in _cache:
+        sc = {"ico4": lambda: rt.scenes.icosphere_scene(4), "ico6": lambda: rt.scenes.icosphere_scene(6),
+              "mixed2": lambda: rt.scenes.mixed_scene(2), "spheres": rt.scenes.sphere_plane_scene}[tag]()
+        tkey = ("tree", tag)
+        if tkey not in _cache:
+            _cache[tkey] = orc.KdTree(sc.verts4, sc.idx4) if sc.idx4.shape[0] else None
+        tree = _cache[tkey]
+        prog = refcl.RefProgram(tag, flavour)
+        rs = refcl.RefScene(prog, sc, tree.blob if tree is not None else None)
+        _cache[key] = (sc, tree, rs)
+    return _cache[key]
+
+
+def ulps(a, b):
+    """Distance in units in the last place between two float32 arrays (0 for equal bit patterns, +0 == -0)."""
+    a = np.ascontiguousarray(a, np.float32).view(np.int32).astype(np.int64)
+    b = np.ascontiguousarray(b, np.float32).view(np.int32).astype(np.int64)
+    a = np.where(a < 0, -(a & 0x7fffffff), a)
+    b = np.where(b < 0, -(b & 0x7fffffff), b)
+    return np.abs(a - b)
+
+
+def _test_rays(orc, sc, tree, w, h, seed, bounces):
+    """Primary rays, the wiped (all-zero) rays of the first iteration, `bounces` generations of incoherent
+    bounce rays from the oracle's own run, and hand-made rays with exact zeros in the direction."""
+    st = oracle_spath_run(orc, sc, tree, w, h, seed, 0)
+    sets = [st.primary_rays, st.first_bounce_rays, st.rays.copy()]
+    from raytracer_amd.scenes import splitmix32
+    rv = splitmix32(seed + 1, np.arange(0, bounces + 1, dtype=np.uint64))
+    for k in range(bounces):
+        st.iterate(int(rv[k + 1]))
+        sets.append(st.rays.copy())
+    rng = np.random.RandomState(seed)
+    n = 4096
+    extra = np.zeros((n, 8), np.float32)
+    extra[:, 0:3] = rng.uniform(-35, 35, size=(n, 3))
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    for k in range(n // 2):
+        d[k, rng.randint(3)] = (0.0, -0.0, 1.0, -1.0)[rng.randint(4)]
+    extra[:, 4:7] = d
+    sets.append(extra)
+    rays = np.ascontiguousarray(np.concatenate(sets))
+    keep = tree.ray_stack(rays) <= 16
+    assert keep.mean() > 0.99
+    rays = rays[keep]
+    return np.ascontiguousarray(rays[: rays.shape[0] // 64 * 64])
+
+
+def test_integer_kernels_bit_exact(orc, refcl, rt):
+    """xorshift_batch and f_buffer_to_byte_buffer_avg (src/kernels/path.cl:421-444): integer work and one
+    division per channel; the reference kernels, the oracle and the library agree bit for bit."""
+    import ctypes as C
+    _, _, rs = _scene(rt, orc, refcl, "ico4", "strict")
+    n = 64 * 257
+    rng = np.random.RandomState(1)
+    data = rng.randint(0, 1 << 32, size=n, dtype=np.uint64).astype(np.uint32)
+    d = refcl.DevBuf.of(data)
+    rs.prog.launch("xorshift_batch", [d], n)
+    want = data.copy()
+    orc.xorshift(want)
+    assert_bits_equal(d.read(np.uint32, n), want, "xorshift_batch")
+
+    tex = rng.uniform(-0.5, 40.0, size=(n, 4)).astype(np.float32)
+    tex[:, 3] = rng.randint(0, 40, size=n)
+    tex[::97] = 0
+    out = refcl.DevBuf.zeros(4 * n)
+    rs.prog.launch("f_buffer_to_byte_buffer_avg", [out, refcl.DevBuf.of(tex), refcl.DevBuf.zeros(48 * n), 64, 0], n)
+    got = out.read(np.uint32, n)
+    want = np.zeros(n, np.uint32)
+    orc.lib().orc_resolve_avg(want.ctypes.data_as(C.c_void_p), tex.ctypes.data_as(C.c_void_p), C.c_uint32(n))
+    differ = int((got != want).sum())
+    # the default `/` of OpenCL C is allowed 2.5 ulp; the strict flavour's is correctly rounded like the oracle's
+    assert differ == 0, f"{differ} of {n} packed pixels differ"
+
+
+def test_generate_rays_within_2_ulp(orc, refcl, rt):
+    """generate_rays (src/kernels/ray.cl:109-133) goes through the built-in normalize (rsqrt based in ROCm's
+    library, sqrt + divide in the oracle): directions agree to 2 ulp, origins exactly."""
+    _, _, rs = _scene(rt, orc, refcl, "ico4", "strict")
+    for (w, h) in ((64, 64), (128, 96)):
+        rays = refcl.DevBuf.zeros(32 * w * h)
+        rs.generate_rays(rays, w, h)
+        got = rays.read(np.float32, 8 * w * h).reshape(-1, 8)
+        want = orc.generate_rays(w, h)
+        assert_bits_equal(got[:, 0:4], want[:, 0:4], "ray origins")
+        assert ulps(got[:, 4:8], want[:, 4:8]).max() <= 2
+
+
+@pytest.mark.parametrize("tag,w,h,bounces", [("ico4", 128, 128, 6), ("ico6", 256, 256, 5)])
+def test_traversal_reference_kernel_equals_oracle_and_library(orc, refcl, rt, tag, w, h, bounces):
+    """kdtree_intersection (src/kernels/kdtree.cl:90-321) as compiled from the reference, on primary, wiped,
+    bounce and hand-made rays:
+      * every word of every hit record equals the oracle's when the oracle uses ROCm's dot/cross/min/max;
+      * with the plain definitions (the ones the library is built to) the same triangle is found for every ray
+        and t/u/v agree to rounding: |dt| <= 1e-5 of the largest t; u and v, whose error grows with 1/det for
+        thin or edge-on triangles, to 1e-4 absolute for 99 % of the rays and 5e-3 for all;
+      * the library's kernel, through the C API, equals the plain oracle bit for bit on the same rays."""
+    import ctypes as C
+    sc, tree, rs = _scene(rt, orc, refcl, tag, "strict")
+    rays = _test_rays(orc, sc, tree, w, h, 11, bounces)
+    n = rays.shape[0]
+    d_rays, d_hits = refcl.DevBuf.of(rays), refcl.DevBuf.zeros(16 * n)
+    rs.kd_intersect(d_hits, d_rays, n)
+    got = d_hits.read(refcl.HIT_DT, n)
+
+    orc.set_builtins("rocm")
+    try:
+        want_rocm = tree.intersect(rays)
+    finally:
+        orc.set_builtins("plain")
+    hits_equal(got, want_rocm, "reference kernel vs oracle (ROCm built-ins)")
+
+    want = tree.intersect(rays)
+    hit = want["t"] != 0
+    assert 0.3 < hit.mean() < 0.999
+    same = got["tri"] == want["tri"]
+    assert same.all(), f"{int((~same).sum())} of {n} rays find another triangle"
+    assert np.abs(got["t"][hit] - want["t"][hit]).max() <= 1e-5 * np.abs(want["t"][hit]).max()
+    duv = np.maximum(np.abs(got["u"] - want["u"]), np.abs(got["v"] - want["v"]))
+    print(f"{tag}: u/v differences: max {duv.max():.2e}, within 1e-5 {float((duv <= 1e-5).mean()):.4f}, within 1e-4 {float((duv <= 1e-4).mean()):.4f}")
+    assert duv.max() <= 5e-3 and (duv <= 1e-4).mean() >= 0.99
+
+    r = rt.Renderer(sc, 8, 8).build()
+    r.L.raytracer_prepass(r.rctx)
+    ro = r.L.rt_mem_alloc(r.dev, 16 * n); rd = r.L.rt_mem_alloc(r.dev, 16 * n); hits = r.L.rt_mem_alloc(r.dev, 16 * n)
+    r.upload(ro, np.ascontiguousarray(rays[:, 0:4])); r.upload(rd, np.ascontiguousarray(rays[:, 4:8]))
+    r.L.rt_k_kd_intersect(r.dev, C.byref(r.kdt.view), ro, rd, hits, n)
+    r.sync()
+    lib_hits = r.download(hits, np.uint32, 4 * n).reshape(n, 4)
+    assert_bits_equal(lib_hits[:, 0], want["tri"], "library vs oracle: index offset")
+    assert_bits_equal(lib_hits[:, 0], got["tri"], "library vs reference kernel: index offset")
+    for k, f in ((1, "t"), (2, "u"), (3, "v")):
+        assert_bits_equal(lib_hits[:, k], want[f].view(np.uint32), f"library vs oracle: {f}")
+    for m in (ro, rd, hits):
+        r.L.rt_mem_free(r.dev, m)
+    r.close()
+
+
+def test_traversal_default_flavour_finds_the_same_triangles(orc, refcl, rt):
+    """The flavour clBuildProgram(NULL options) gives (contraction allowed, 2.5-ulp division): hit records are no
+    longer bit-equal to anything, but the triangle found is the same for all but grazing rays.  Stated tolerance:
+    at most 1 ray in 10,000 finds another triangle."""
+    sc, tree, rs = _scene(rt, orc, refcl, "ico4", "default")
+    rays = _test_rays(orc, sc, tree, 128, 128, 12, 4)
+    n = rays.shape[0]
+    d_hits = refcl.DevBuf.zeros(16 * n)
+    rs.kd_intersect(d_hits, refcl.DevBuf.of(rays), n)
+    got = d_hits.read(refcl.HIT_DT, n)
+    want = tree.intersect(rays)
+    other = int((got["tri"] != want["tri"]).sum())
+    assert other <= n // 10000, f"{other} of {n} rays find another triangle"
+
+
+def test_shading_kernels_one_step_at_a_time(orc, refcl, rt):
+    """segmented_path_trace_init and segmented_path_trace (src/kernels/path.cl:36-258), one launch at a time on
+    the oracle's state: before every step the reference kernels' buffers are set to the oracle's, then both take
+    the step.  Integer fields (sample and bounce counters, hit records carried over) must be equal; floats go
+    through normalize / sqrt / sin / cos of ROCm's library on one side and the oracle's on the other: rays to
+    1e-5 absolute (unit directions, positions of order 10), path weights and accumulated radiance to 1e-5
+    relative to their scale."""
+    sc, tree, rs = _scene(rt, orc, refcl, "ico4", "strict")
+    w, h, seed, iters = 96, 64, 21, 10
+    from raytracer_amd.scenes import splitmix32
+    n = w * h
+    rb = splitmix32(seed, np.arange(n, dtype=np.uint64))
+    rv = splitmix32(seed + 1, np.arange(iters + 1, dtype=np.uint64))
+    o = orc.SpathState(sc, tree, w, h)
+    g = refcl.RefSpath(rs, w, h)
+    o.prepass(rb, int(rv[0]))
+    g.prepass(rb, int(rv[0]))
+    # init kernel: primary hits came from each side's own traversal of its own primary rays (2 ulp apart)
+    assert (g.source_results["tri"] == o.source_results["tri"]).mean() > 0.999
+    assert np.abs(g.first_bounce_rays - o.first_bounce_rays).max() < 2e-4
+    finished = 0
+    # every step: the oracle's pre-step state and its traversal result go to the reference shading kernel
+    o = orc.SpathState(sc, tree, w, h)
+    o.prepass(rb, int(rv[0]))
+    for k in range(iters):
+        pre = {"out_tex": o.out_tex.copy(), "rays": o.rays.copy(), "progress": o.progress.copy(),
+               "random": o.random.copy()}
+        o.iterate(int(rv[k + 1]))                  # xorshift, traversal (-> o.results), shading
+        g.d_out_tex.write(pre["out_tex"]); g.d_rays.write(pre["rays"]); g.d_progress.write(pre["progress"])
+        g.d_random.write(pre["random"]); g.d_origin_rays.write(o.origin_rays)
+        g.d_source_results.write(o.source_results); g.d_results.write(o.results)
+        rs.prog.launch("xorshift_batch", [g.d_random], n)
+        rs.prog.launch("segmented_path_trace",
+                       [g.d_out_tex, g.d_rays, g.d_origin_rays, g.d_results, g.d_source_results, g.d_progress,
+                        g.d_random, rs.materials, rs.meshes, rs.indices, rs.vertices, rs.normals, w, int(rv[k + 1])], n)
+        gp, op = g.progress, o.progress
+        assert_bits_equal(gp[:, 0:2], op[:, 0:2], f"iteration {k + 1}: sample / bounce counters")
+        assert_bits_equal(g.random, o.random, f"iteration {k + 1}: random buffer")
+        assert np.abs(g.rays - o.rays).max() <= 1e-5 * max(1.0, np.abs(o.rays).max()), f"iteration {k + 1}: rays"
+        gm, om = gp[:, 4:7].view(np.float32), op[:, 4:7].view(np.float32)
+        ga, oa = gp[:, 8:11].view(np.float32), op[:, 8:11].view(np.float32)
+        assert np.abs(gm - om).max() <= 1e-5 * max(1.0, np.abs(om).max()), f"iteration {k + 1}: mask"
+        assert np.abs(ga - oa).max() <= 1e-5 * max(1.0, np.abs(oa).max()), f"iteration {k + 1}: accumulated colour"
+        assert np.abs(g.out_tex - o.out_tex).max() <= 1e-5 * max(1.0, np.abs(o.out_tex).max()), f"iteration {k + 1}: out_tex"
+        finished = max(finished, int(o.out_tex[:, 3].max()))
+    assert finished >= 2
+
+
+def test_radiance_end_to_end_against_the_library(orc, refcl, rt):
+    """The whole split path tracer, free running on both sides with the same RNG streams: the reference's kernels
+    (default flavour, as the reference would build them) against the library through its C API.  A path is
+    chaotic -- a last-bit difference in a bounce direction can send it to another triangle -- so pixels are not
+    expected to be equal one by one for long; the radiance is.  Stated tolerance at 16 samples per pixel (64
+    iterations): RMSE of the averaged linear image below 2e-3, image means within 1e-3, 8-bit channels of the
+    resolved frames within one level for 99 % of the pixels.  (Measured on this scene: RMSE 7e-9, every pixel
+    within 1e-5 -- after 64 iterations no path had left its twin yet.)"""
+    sc, tree, rs = _scene(rt, orc, refcl, "ico4", "default")
+    w, h, seed, iters = 128, 128, 31, 64
+    from raytracer_amd.scenes import splitmix32
+    n = w * h
+    rb = splitmix32(seed, np.arange(n, dtype=np.uint64))
+    rv = splitmix32(seed + 1, np.arange(iters + 1, dtype=np.uint64))
+    g = refcl.RefSpath(rs, w, h)
+    g.prepass(rb, int(rv[0]))
+    for k in range(iters):
+        g.iterate(int(rv[k + 1]))
+    r = rt.Renderer(sc, w, h).build()
+    r.init_spath(seed=seed, resolve_interval=0)
+    r.spath_prepass(iters)
+    r.spath_render(iters)
+    lib = r.spath_state()
+    ref_tex, lib_tex = g.out_tex, lib["out_tex"]
+    ref_img = ref_tex[:, :3] / np.maximum(ref_tex[:, 3:4], 1)
+    lib_img = lib_tex[:, :3] / np.maximum(lib_tex[:, 3:4], 1)
+    rmse = float(np.sqrt(np.mean((ref_img - lib_img) ** 2)))
+    same_pixels = float((np.abs(ref_img - lib_img).max(axis=1) < 1e-5).mean())
+    print(f"radiance RMSE {rmse:.3e}, mean {ref_img.mean():.5f} vs {lib_img.mean():.5f}, pixels equal to 1e-5: {same_pixels:.4f}")
+    assert abs(float(ref_img.mean()) - float(lib_img.mean())) < 1e-3
+    assert same_pixels > 0.9
+    assert rmse < 2e-3
+    img_ref, img_lib = g.resolve(), r.spath_resolve()
+    ch = lambda a, s: ((a >> s) & 0xff).astype(np.int32)
+    worst = np.max([np.abs(ch(img_ref, s) - ch(img_lib, s)) for s in (0, 8, 16)], axis=0)
+    assert (worst <= 1).mean() > 0.99
+    r.close()
+
+
+@pytest.mark.parametrize("tag,w,h", [("spheres", 128, 128), ("mixed2", 96, 64)])
+def test_cast_ray_test_reference_kernel(orc, refcl, rt, tag, w, h):
+    """cast_ray_test (src/kernels/ray.cl:15-105; spheres, planes, brute-force meshes, shadow and mirror rays) as
+    compiled from the reference against the oracle image, which the library reproduces bit for bit
+    (test_gpu_integrators.py).  The kernel's sphere, shadow and mirror code goes through the built-in normalize,
+    sqrt and dot, so silhouette and shadow-edge pixels can fall the other way.  Stated tolerance: at least 99.5 %
+    of the packed pixels equal (measured: 99.87 % and 99.90 %)."""
+    sc, _, rs = _scene(rt, orc, refcl, tag, "strict")
+    rays = orc.generate_rays(w, h)
+    out = refcl.DevBuf.zeros(4 * w * h)
+    rs.cast_ray_test(out, refcl.DevBuf.of(rays), w, h)
+    got = out.read(np.uint32, w * h)
+    want = orc.cast_ray_test(sc, rays)
+    equal = float((got == want).mean())
+    ch = lambda a, s: ((a >> s) & 0xff).astype(np.int32)
+    worst = np.max([np.abs(ch(got, s) - ch(want, s)) for s in (0, 8, 16, 24)], axis=0)
+    print(f"cast_ray_test {tag}: {equal:.4f} of pixels equal, {float((worst <= 2).mean()):.4f} within 2 levels")
+    assert equal > 0.995
+    assert len(np.unique(got)) > 20
