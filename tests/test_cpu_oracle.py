@@ -148,3 +148,68 @@ def test_primary_visibility_matches_the_reference_stored_render(rt, orc):
     tree = orc.KdTree(sc.verts4, sc.idx4)
     st = oracle_spath_run(orc, sc, tree, w, h, 1, 0)
     check_against_stored_render(sc, st.source_results, emitter, objects)
+
+
+def test_rocm_builtin_mode_changes_only_rounding(rt, orc):
+    """The oracle's second definition of dot / cross / min / max (the one ROCm's OpenCL library has, used to hold
+    the reference's compiled kernels against the oracle bit for bit on the GPU) is the same algorithm: on camera
+    and random rays it finds the same triangles, t agrees to rounding, and some low bits do differ."""
+    sc = rt.scenes.icosphere_scene(3)
+    tree = orc.KdTree(sc.verts4, sc.idx4)
+    rays = orc.generate_rays(96, 96)
+    rng = np.random.RandomState(3)
+    extra = np.zeros((4096, 8), np.float32)
+    extra[:, 0:3] = rng.uniform(-20, 20, size=(4096, 3))
+    d = rng.normal(size=(4096, 3)).astype(np.float32)
+    extra[:, 4:7] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.ascontiguousarray(np.concatenate([rays, extra]))
+    plain = tree.intersect(rays)
+    orc.set_builtins("rocm")
+    try:
+        rocm = tree.intersect(rays)
+    finally:
+        orc.set_builtins("plain")
+    again = tree.intersect(rays)
+    assert np.array_equal(plain.view(np.uint32), again.view(np.uint32))          # the switch leaves nothing behind
+    assert (plain["tri"] != rocm["tri"]).mean() <= 1e-4
+    same = plain["tri"] == rocm["tri"]
+    assert np.abs(plain["t"][same] - rocm["t"][same]).max() <= 1e-5 * np.abs(plain["t"]).max()
+    assert (plain["t"].view(np.uint32) != rocm["t"].view(np.uint32)).any()
+    assert tree.ray_stack(rays).max() <= 16
+
+
+def test_reference_kernel_build_matches_the_reference_host_calls():
+    """Where oracle/_ref holds the code objects compiled from the reference's kernel files, their metadata must
+    show the argument lists the reference's host code sets (counts of clSetKernelArg calls in
+    src/spath_raytracer.c:143-155,258-263,287-303,325-345, src/raytracer.c:187-190, src/ss_raytracer.c:14-25)."""
+    import json
+    import os
+    base = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref")
+    path = os.path.join(base, "refcl_ico4_strict.json")
+    if not os.path.exists(path):
+        pytest.skip("reference kernels not built here")
+    meta = json.load(open(path))
+    want = {"kdtree_intersection": 8, "segmented_path_trace_init": 13, "segmented_path_trace": 14, "generate_rays": 4,
+            "xorshift_batch": 1, "f_buffer_to_byte_buffer_avg": 5, "cast_ray_test": 12}
+    for name, count in want.items():
+        args = [a for a in meta["kernels"][name]["args"] if not a["kind"].startswith("hidden")]
+        assert len(args) == count, name
+    images = [a for a in meta["kernels"]["kdtree_intersection"]["args"] if a["kind"] == "image"]
+    assert len(images) == 2 and all(a["size"] == 8 for a in images)
+    assert meta["macros"]["BLOCKSIZE_X"] == "64" and meta["macros"]["SCENE_MIN"].count(",") == 2
+    for flavour in ("default", "strict"):
+        assert os.path.getsize(os.path.join(base, f"refcl_ico4_{flavour}.hsaco")) > 50_000
+
+
+def test_hsa_launcher_exports(orc):
+    """oracle/libhsa_runner.so (the launcher for those code objects) loads and exports its entry points; nothing
+    is called here, a GPU is needed for that."""
+    import ctypes as C
+    import os
+    path = os.path.join(os.path.dirname(orc.__file__), "libhsa_runner.so")
+    if not os.path.exists(path):
+        pytest.skip("no HSA headers here: launcher not built")
+    L = C.CDLL(path)
+    for name in ("hr_init", "hr_alloc", "hr_free", "hr_h2d", "hr_d2h", "hr_fill32", "hr_load", "hr_kernel_info",
+                 "hr_dispatch", "hr_last_error", "hr_agent_name"):
+        assert hasattr(L, name), name
