@@ -24,10 +24,15 @@
  *   Builder + serialiser: PINNED.  oracle/_ref builds the reference's own
  *   kdtree.c/geom.c from /root/reference and tests compare blobs byte for byte
  *   (padding bytes, which the reference leaves uninitialised, are masked).
- *   Device kernels: PARITY UNPINNED.  The reference has no tests or golden
- *   vectors, and its OpenCL C kernels cannot be built here without writing
- *   stand-ins for an OpenCL built-in library that the image lacks, so this
- *   file is a reading of the kernel sources, not a checked copy of them.
+ *   Device kernels: PINNED against the reference's own kernels.  The kernel
+ *   files compile unmodified for gfx950 with ROCm's clang and OpenCL library
+ *   (oracle/build_ref_kernels.py -> oracle/_ref/); tests/test_gpu_refkernels.py
+ *   runs them on the GPU (oracle/refcl.py) and holds them against this file:
+ *   kdtree_intersection bit for bit once dot/cross/min/max are defined as
+ *   ROCm's library defines them (orc_set_builtins(1)), the shading kernels one
+ *   step at a time to 1e-5, whole renders as radiance.  A host build of the
+ *   kernels would need stand-ins for an OpenCL built-in library and is not
+ *   attempted.
  *
  * Arithmetic conventions (the OpenCL spec leaves these to the implementation;
  * this oracle fixes ONE conformant choice so a GPU result can be compared bit
