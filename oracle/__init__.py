@@ -115,8 +115,9 @@ def _p(a):
 
 
 def set_builtins(mode: str) -> None:
-    """'plain' (default): dot/cross/min/max as the header of oracle_rt.c defines them; 'rocm': as ROCm's OpenCL
-    library defines them on gfx950, for bit-for-bit comparisons with the reference's kernels run there."""
+    """'rocm' (default): dot/cross/min/max as ROCm's OpenCL library defines them on gfx950 -- what the reference's
+    kernels compute when built for this GPU, and what the library is built to; 'plain': sums left to right, textbook
+    cross, select-style min/max."""
     lib().orc_set_builtins(C.c_int({"plain": 0, "rocm": 1}[mode]))
 
 

@@ -3,8 +3,13 @@
 // Arithmetic contract: results must be bit-identical to a plain IEEE-754
 // single-precision evaluation in source order, so this file is built with
 // -ffp-contract=off and without any fast-math option; divisions and square
-// roots are the correctly rounded ones.  min/max follow OpenCL's
-// "y < x ? y : x" definitions, dot products are summed left to right.
+// roots are the correctly rounded ones.  The OpenCL built-ins whose rounding
+// the specification leaves open are defined as ROCm's OpenCL library defines
+// them on this GPU, so that hit records equal, bit for bit, what the
+// reference's own kernels give when ROCm's compiler builds them (without
+// contraction, with correctly rounded division) for the same device:
+// dot(a,b) = fma(a.z,b.z, fma(a.y,b.y, a.x*b.x)), cross with one fma per
+// component, min/max = IEEE minNum/maxNum.
 #include "rt_internal.hpp"
 
 #define RT_INF __builtin_huge_valf()
@@ -22,13 +27,17 @@ __device__ __forceinline__ f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y 
 __device__ __forceinline__ f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
 __device__ __forceinline__ f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
 __device__ __forceinline__ f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
-__device__ __forceinline__ float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ float dot3(f3 a, f3 b)
+{
+    return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x));
+}
 __device__ __forceinline__ f3 cross3(f3 a, f3 b)
 {
-    return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+    return mk3(__builtin_fmaf(a.y, b.z, -(b.y * a.z)), __builtin_fmaf(a.z, b.x, -(b.z * a.x)),
+               __builtin_fmaf(a.x, b.y, -(b.x * a.y)));
 }
-__device__ __forceinline__ float cl_min(float a, float b) { return b < a ? b : a; }
-__device__ __forceinline__ float cl_max(float a, float b) { return a < b ? b : a; }
+__device__ __forceinline__ float cl_min(float a, float b) { return __builtin_fminf(a, b); }
+__device__ __forceinline__ float cl_max(float a, float b) { return __builtin_fmaxf(a, b); }
 __device__ __forceinline__ f3 normalize3(f3 a)
 {
     float len = sqrtf(dot3(a, a));

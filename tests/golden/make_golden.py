@@ -7,9 +7,12 @@ kd_ico2.npz   serialised kd-tree of scenes.icosphere_scene(2) from the
               struct padding uninitialised).  Needs the reference checkout.
 spath_ico3.npz  oracle outputs for a 48x32 render of icosphere_scene(3):
               primary hits, and out_tex / progress after 6 iterations with the
-              counter-based RNG streams (seed 11).  These pin the oracle against
-              its own earlier output (the reference has no vectors for the
-              kernels), so a change in them is a deliberate, reviewed event.
+              counter-based RNG streams (seed 11), in the oracle's default
+              arithmetic (dot/cross/min/max as ROCm's OpenCL library defines
+              them).  These pin the oracle against its own earlier output (the
+              reference has no vectors for the kernels; its compiled kernels are
+              held against the oracle on the GPU, tests/test_gpu_refkernels.py),
+              so a change in them is a deliberate, reviewed event.
 ss_sphere_plane.npz  oracle outputs for the sphere + plane scene of res/scenes/path_test.rsc at 96x64: the
               SS integrator's packed image and the PATH integrator's first sample (regression only,
               like spath_ico3.npz).

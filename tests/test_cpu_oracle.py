@@ -150,10 +150,11 @@ def test_primary_visibility_matches_the_reference_stored_render(rt, orc):
     check_against_stored_render(sc, st.source_results, emitter, objects)
 
 
-def test_rocm_builtin_mode_changes_only_rounding(rt, orc):
-    """The oracle's second definition of dot / cross / min / max (the one ROCm's OpenCL library has, used to hold
-    the reference's compiled kernels against the oracle bit for bit on the GPU) is the same algorithm: on camera
-    and random rays it finds the same triangles, t agrees to rounding, and some low bits do differ."""
+def test_builtin_modes_differ_only_in_rounding(rt, orc):
+    """The oracle's two definitions of dot / cross / min / max -- ROCm's OpenCL library's (the default: what the
+    reference's compiled kernels compute on the GPU, bit for bit, and what the library is built to) and the plain
+    one -- are the same algorithm: on camera and random rays they find the same triangles, t agrees to rounding,
+    and some low bits do differ."""
     sc = rt.scenes.icosphere_scene(3)
     tree = orc.KdTree(sc.verts4, sc.idx4)
     rays = orc.generate_rays(96, 96)
@@ -163,14 +164,14 @@ def test_rocm_builtin_mode_changes_only_rounding(rt, orc):
     d = rng.normal(size=(4096, 3)).astype(np.float32)
     extra[:, 4:7] = d / np.linalg.norm(d, axis=1, keepdims=True)
     rays = np.ascontiguousarray(np.concatenate([rays, extra]))
-    plain = tree.intersect(rays)
-    orc.set_builtins("rocm")
+    rocm = tree.intersect(rays)
+    orc.set_builtins("plain")
     try:
-        rocm = tree.intersect(rays)
+        plain = tree.intersect(rays)
     finally:
-        orc.set_builtins("plain")
+        orc.set_builtins("rocm")
     again = tree.intersect(rays)
-    assert np.array_equal(plain.view(np.uint32), again.view(np.uint32))          # the switch leaves nothing behind
+    assert np.array_equal(rocm.view(np.uint32), again.view(np.uint32))          # the switch leaves nothing behind
     assert (plain["tri"] != rocm["tri"]).mean() <= 1e-4
     same = plain["tri"] == rocm["tri"]
     assert np.abs(plain["t"][same] - rocm["t"][same]).max() <= 1e-5 * np.abs(plain["t"]).max()

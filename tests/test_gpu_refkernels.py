@@ -6,13 +6,12 @@ mounted; the built files travel to the GPU box, the sources do not).  oracle/ref
 with the reference's own argument lists.  These tests tie the three statements of the path together:
 
     reference kernels (flavour "strict": no contraction, correctly rounded / and sqrt)
-        == oracle with ROCm's definitions of dot / cross / min / max       bit for bit (traversal)
-    oracle with the plain definitions == the library                        bit for bit (the other GPU tests)
+        == oracle == the library's kernel through the C API            bit for bit (traversal: every hit record)
 
-so that the only thing between the reference's kernels and the library is the definition of four OpenCL
-built-ins, which the OpenCL specification leaves to the implementation.  Shading goes through more built-ins
-(normalize, sqrt, sin, cos): it is compared one kernel step at a time on identical inputs, within a few ulp, and
-end to end as radiance.
+The oracle and the library define the four OpenCL built-ins on that path whose rounding the specification leaves
+open (dot, cross, min, max) as ROCm's OpenCL library does -- the implementation that builds the reference for this
+GPU.  Shading goes through more built-ins (normalize, sqrt, sin, cos), where the oracle and the library share their
+own definitions: it is compared one kernel step at a time on identical inputs, to 1e-5, and end to end as radiance.
 
 The reference's traversal keeps a private stack of 16 entries without a bounds check (src/kernels/kdtree.cl:78,120):
 rays that would need more are never handed to its kernel here (checked per ray with the oracle first).
@@ -131,11 +130,13 @@ def test_generate_rays_within_2_ulp(orc, refcl, rt):
 def test_traversal_reference_kernel_equals_oracle_and_library(orc, refcl, rt, tag, w, h, bounces):
     """kdtree_intersection (src/kernels/kdtree.cl:90-321) as compiled from the reference, on primary, wiped,
     bounce and hand-made rays:
-      * every word of every hit record equals the oracle's when the oracle uses ROCm's dot/cross/min/max;
-      * with the plain definitions (the ones the library is built to) the same triangle is found for every ray
-        and t/u/v agree to rounding: |dt| <= 1e-5 of the largest t; u and v, whose error grows with 1/det for
-        thin or edge-on triangles, to 1e-4 absolute for 99 % of the rays and 5e-3 for all;
-      * the library's kernel, through the C API, equals the plain oracle bit for bit on the same rays."""
+      * every word of every hit record equals the oracle's;
+      * every word of every hit record of the library's kernel, through the C API, equals them too;
+      * with the plain definitions of dot/cross/min/max (sums left to right, select-style min/max) the oracle
+        still finds the same triangle for all but grazing rays (at most 1 in 10,000; measured 1 in 150,000 and
+        none in 530,000) and t/u/v agree to rounding: |dt| <= 1e-5 of the largest t;
+        u and v, whose error grows with 1/det for thin or edge-on triangles, to 1e-4 absolute for 99 % of the
+        rays and 5e-3 for all -- that is all the choice of definition is worth."""
     import ctypes as C
     sc, tree, rs = _scene(rt, orc, refcl, tag, "strict")
     rays = _test_rays(orc, sc, tree, w, h, 11, bounces)
@@ -144,20 +145,21 @@ def test_traversal_reference_kernel_equals_oracle_and_library(orc, refcl, rt, ta
     rs.kd_intersect(d_hits, d_rays, n)
     got = d_hits.read(refcl.HIT_DT, n)
 
-    orc.set_builtins("rocm")
-    try:
-        want_rocm = tree.intersect(rays)
-    finally:
-        orc.set_builtins("plain")
-    hits_equal(got, want_rocm, "reference kernel vs oracle (ROCm built-ins)")
-
     want = tree.intersect(rays)
+    hits_equal(got, want, "reference kernel vs oracle")
     hit = want["t"] != 0
     assert 0.3 < hit.mean() < 0.999
-    same = got["tri"] == want["tri"]
-    assert same.all(), f"{int((~same).sum())} of {n} rays find another triangle"
-    assert np.abs(got["t"][hit] - want["t"][hit]).max() <= 1e-5 * np.abs(want["t"][hit]).max()
-    duv = np.maximum(np.abs(got["u"] - want["u"]), np.abs(got["v"] - want["v"]))
+
+    orc.set_builtins("plain")
+    try:
+        plain = tree.intersect(rays)
+    finally:
+        orc.set_builtins("rocm")
+    same = got["tri"] == plain["tri"]
+    print(f"{tag}: {int((~same).sum())} of {n} rays find another triangle under the plain definitions")
+    assert (~same).sum() <= n // 10000
+    assert np.abs(got["t"][same] - plain["t"][same]).max() <= 1e-5 * np.abs(plain["t"][hit]).max()
+    duv = np.maximum(np.abs(got["u"] - plain["u"]), np.abs(got["v"] - plain["v"]))[same]
     print(f"{tag}: u/v differences: max {duv.max():.2e}, within 1e-5 {float((duv <= 1e-5).mean()):.4f}, within 1e-4 {float((duv <= 1e-4).mean()):.4f}")
     assert duv.max() <= 5e-3 and (duv <= 1e-4).mean() >= 0.99
 
@@ -168,10 +170,9 @@ def test_traversal_reference_kernel_equals_oracle_and_library(orc, refcl, rt, ta
     r.L.rt_k_kd_intersect(r.dev, C.byref(r.kdt.view), ro, rd, hits, n)
     r.sync()
     lib_hits = r.download(hits, np.uint32, 4 * n).reshape(n, 4)
-    assert_bits_equal(lib_hits[:, 0], want["tri"], "library vs oracle: index offset")
     assert_bits_equal(lib_hits[:, 0], got["tri"], "library vs reference kernel: index offset")
     for k, f in ((1, "t"), (2, "u"), (3, "v")):
-        assert_bits_equal(lib_hits[:, k], want[f].view(np.uint32), f"library vs oracle: {f}")
+        assert_bits_equal(lib_hits[:, k], got[f].view(np.uint32), f"library vs reference kernel: {f}")
     for m in (ro, rd, hits):
         r.L.rt_mem_free(r.dev, m)
     r.close()
