@@ -60,11 +60,17 @@ SIMT_WIDTH = 64
 def scene_specs():
     """Scenes the GPU tests run the reference kernels on: tag -> SceneArrays."""
     from raytracer_amd import scenes
+    z = np.load(os.path.join(ROOT, "tests", "golden", "ref_render_path_obj2.npz"))      # the reference's own scene file
+    path_obj2 = scenes.SceneArrays(verts4=z["verts4"], normals4=z["normals4"], idx4=z["idx4"],
+                                   meshes=z["meshes"].view(scenes.MESH_DT).reshape(-1),
+                                   materials=z["materials"].view(scenes.MATERIAL_DT).reshape(-1),
+                                   spheres=np.zeros(0, scenes.SPHERE_DT), planes=np.zeros(0, scenes.PLANE_DT))
     return {
         "ico4": scenes.icosphere_scene(4),
         "ico6": scenes.icosphere_scene(6),
         "mixed2": scenes.mixed_scene(2),
         "spheres": scenes.sphere_plane_scene(),
+        "path_obj2": path_obj2,
     }
 
 

@@ -38,8 +38,10 @@ _cache = {}
 def _scene(rt, orc, refcl, tag, flavour):
     key = (tag, flavour)
     if key not in _cache:
+        from helpers import load_ref_render_fixture
         sc = {"ico4": lambda: rt.scenes.icosphere_scene(4), "ico6": lambda: rt.scenes.icosphere_scene(6),
-              "mixed2": lambda: rt.scenes.mixed_scene(2), "spheres": rt.scenes.sphere_plane_scene}[tag]()
+              "mixed2": lambda: rt.scenes.mixed_scene(2), "spheres": rt.scenes.sphere_plane_scene,
+              "path_obj2": lambda: load_ref_render_fixture(rt)[0]}[tag]()
         tkey = ("tree", tag)
         if tkey not in _cache:
             _cache[tkey] = orc.KdTree(sc.verts4, sc.idx4) if sc.idx4.shape[0] else None
@@ -322,3 +324,38 @@ def test_path_trace_reference_kernel(orc, refcl, rt):
     assert np.isfinite(got).all()
     assert close >= 0.99
     assert rmse < 1e-2
+
+
+def test_reference_scene_on_reference_kernels(orc, refcl, rt):
+    """The reference's own scene file (res/scenes/path_obj2.rsc, as tests/golden/ref_render_path_obj2.npz holds
+    it) at the 1920x1080 of the frame the reference stores of it, on the reference's own generate_rays and
+    kdtree_intersection kernels: the hits show the stored frame's emitter silhouette pixel for pixel, and on the
+    same rays the library's traversal returns the same hit records bit for bit."""
+    import ctypes as C
+    from helpers import load_ref_render_fixture, check_against_stored_render
+    if not refcl.available("path_obj2", "strict"):
+        pytest.skip("no code object for this scene")
+    sc, w, h, emitter, objects = load_ref_render_fixture(rt)
+    _, tree, rs = _scene(rt, orc, refcl, "path_obj2", "strict")
+    n = w * h
+    assert n % 64 == 0
+    d_rays, d_hits = refcl.DevBuf.zeros(32 * n), refcl.DevBuf.zeros(16 * n)
+    rs.generate_rays(d_rays, w, h)
+    rays = d_rays.read(np.float32, 8 * n).reshape(n, 8)
+    assert tree.ray_stack(rays).max() <= 16
+    rs.kd_intersect(d_hits, d_rays, n)
+    got = d_hits.read(refcl.HIT_DT, n)
+    check_against_stored_render(sc, got, emitter, objects)
+    hits_equal(got, tree.intersect(rays), "reference kernel vs oracle on the reference kernel's own rays")
+
+    r = rt.Renderer(sc, 8, 8).build()
+    r.L.raytracer_prepass(r.rctx)
+    ro = r.L.rt_mem_alloc(r.dev, 16 * n); rd = r.L.rt_mem_alloc(r.dev, 16 * n); hits = r.L.rt_mem_alloc(r.dev, 16 * n)
+    r.upload(ro, np.ascontiguousarray(rays[:, 0:4])); r.upload(rd, np.ascontiguousarray(rays[:, 4:8]))
+    r.L.rt_k_kd_intersect(r.dev, C.byref(r.kdt.view), ro, rd, hits, n)
+    r.sync()
+    lib_hits = r.download(hits, np.uint32, 4 * n).reshape(n, 4)
+    assert_bits_equal(lib_hits, got.view(np.uint32).reshape(n, 4), "library vs reference kernel")
+    for m in (ro, rd, hits):
+        r.L.rt_mem_free(r.dev, m)
+    r.close()
