@@ -2,7 +2,7 @@
 """Configuration 2 at full size on the reference's own kernels and on the library: 81,920-triangle mesh scene,
 1024x1024, 64 samples x 4 bounces = 256 iterations, same RNG streams.
 
-    python profiles/ref_kernels_c2_parity.py [iterations] [flavour]
+    python tests/tools/ref_kernels_c2_parity.py [iterations] [flavour]
 
 The reference's kernels (oracle/_ref code objects, launched by oracle/refcl.py) run free, iteration by iteration;
 before each traversal launch the oracle checks every ray's stack depth and the few that would overflow the
@@ -18,7 +18,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 import oracle                       # noqa: E402

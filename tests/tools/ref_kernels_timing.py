@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The reference's own kernels timed on the MI355X, beside the library, on the 82k-triangle workload.
 
-    python profiles/ref_kernels_timing.py [iterations] [flavour]
+    python tests/tools/ref_kernels_timing.py [iterations] [flavour]
 
 Runs the split path tracer's render loop (xorshift_batch -> kdtree_intersection -> segmented_path_trace per
 iteration, src/spath_raytracer.c:355-402) on the code objects compiled from the reference's kernel files
@@ -21,7 +21,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 import oracle                       # noqa: E402
