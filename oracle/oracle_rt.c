@@ -30,7 +30,9 @@
  *   runs them on the GPU (oracle/refcl.py) and holds them against this file:
  *   kdtree_intersection bit for bit once dot/cross/min/max are defined as
  *   ROCm's library defines them (orc_set_builtins(1)), the shading kernels one
- *   step at a time to 1e-5, whole renders as radiance.  A host build of the
+ *   step at a time to 1e-5, whole renders as radiance.  Outputs of those
+ *   kernels are frozen in tests/golden/refkernel_ico4.npz and checked by the
+ *   CPU suite, so the pin holds where there is no GPU.  A host build of the
  *   kernels would need stand-ins for an OpenCL built-in library and is not
  *   attempted.
  *

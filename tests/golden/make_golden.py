@@ -16,6 +16,8 @@ spath_ico3.npz  oracle outputs for a 48x32 render of icosphere_scene(3):
 ss_sphere_plane.npz  oracle outputs for the sphere + plane scene of res/scenes/path_test.rsc at 96x64: the
               SS integrator's packed image and the PATH integrator's first sample (regression only,
               like spath_ico3.npz).
+refkernel_ico4.npz  NOT written here: inputs and outputs of the reference's own kernels run on an MI355X,
+              see make_refkernel_fixture.py.
 obj_cases.npz  small hand-written OBJ texts (quads and n-gons, negative and missing
               indices, CRLF and lone-CR line endings, a last line without line ending,
               groups before / between / after faces, signs and positive exponents)

@@ -214,3 +214,68 @@ def test_hsa_launcher_exports(orc):
     for name in ("hr_init", "hr_alloc", "hr_free", "hr_h2d", "hr_d2h", "hr_fill32", "hr_load", "hr_kernel_info",
                  "hr_dispatch", "hr_last_error", "hr_agent_name"):
         assert hasattr(L, name), name
+
+
+def test_oracle_against_outputs_of_the_reference_kernels(rt, orc):
+    """tests/golden/refkernel_ico4.npz holds inputs and outputs of the REFERENCE's own kernels -- its OpenCL C files
+    compiled unmodified for gfx950 and run on an MI355X (make_refkernel_fixture.py beside it).  The oracle must
+    reproduce them: kdtree_intersection bit for bit on all 22,464 rays (primary, wiped, bounce, hand-made);
+    xorshift_batch bit for bit; segmented_path_trace_init and two iterations of segmented_path_trace from the
+    frozen pre-step buffers: counters and RNG words equal, floats to 1e-5 of their scale (the shading goes through
+    normalize / sin / cos, which ROCm's OpenCL library and the oracle define differently)."""
+    import ctypes as C
+    z = np.load(os.path.join(GOLDEN, "refkernel_ico4.npz"))
+    sc = rt.scenes.icosphere_scene(4)
+    assert hashlib.sha256(sc.verts4.tobytes() + sc.idx4.tobytes()).hexdigest() == str(z["scene_sha256"])
+    tree = orc.KdTree(sc.verts4, sc.idx4)
+    w, h = int(z["width"]), int(z["height"])
+    n = w * h
+    rv = z["random_values"]
+
+    hits_equal(tree.intersect(z["rays"]), z["hits"], "oracle vs reference kernel")
+    assert (z["hits"]["t"] != 0).sum() > 8000 and tree.ray_stack(z["rays"]).max() <= 16
+
+    x = z["xorshift_in"].copy()
+    orc.xorshift(x)
+    assert_bits_equal(x, z["xorshift_out"], "xorshift_batch")
+
+    def close(got, want, what):
+        got, want = np.asarray(got, np.float32), np.asarray(want, np.float32)
+        scale = max(1.0, float(np.abs(want[np.isfinite(want)]).max()))
+        assert np.abs(got - want).max() <= 1e-5 * scale, f"{what}: {np.abs(got - want).max()} (scale {scale})"
+
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    L = orc.lib()
+    st = orc.SpathState(sc, tree, w, h)
+    st.rays = np.ascontiguousarray(z["rays"][:n]).copy()
+    st.results = np.ascontiguousarray(z["init_results"]).copy()
+    L.orc_spath_init(p(st.out_tex), p(st.rays), p(st.origin_rays), p(st.results), p(st.source_results), p(st.progress),
+                     p(sc.idx4), p(sc.normals4), p(sc.meshes), p(sc.materials), C.c_uint32(w), C.c_uint32(h),
+                     C.c_uint32(0), C.c_uint32(int(rv[0])))
+    assert_bits_equal(st.origin_rays, z["init_origin_rays"], "init: origin rays")
+    hits_equal(st.source_results, z["source_results"], "init: source results")
+    assert_bits_equal(st.progress[:, 0:2], z["init_progress"][:, 0:2], "init: counters")
+    close(st.progress[:, 4:7].view(np.float32), z["init_progress"][:, 4:7].view(np.float32), "init: mask")
+    close(st.rays, z["init_rays"], "init: first-bounce rays")
+    close(st.out_tex, z["init_out_tex"], "init: out_tex")
+
+    finished = 0
+    for k in (2, 5):
+        st = orc.SpathState(sc, tree, w, h)
+        st.out_tex = z[f"step_pre_out_tex_{k}"].copy(); st.rays = z[f"step_pre_rays_{k}"].copy()
+        st.progress = z[f"step_pre_progress_{k}"].copy(); st.random = z[f"step_pre_random_{k}"].copy()
+        st.origin_rays = z["origin_rays"].copy(); st.source_results = z["source_results"].copy()
+        st.results = z[f"step_pre_results_{k}"].copy()
+        orc.xorshift(st.random)
+        L.orc_spath_trace(p(st.out_tex), p(st.rays), p(st.origin_rays), p(st.results), p(st.source_results),
+                          p(st.progress), p(st.random), p(sc.idx4), p(sc.normals4), p(sc.meshes), p(sc.materials),
+                          C.c_uint32(n), C.c_uint32(int(rv[k])), C.c_int(4))
+        post = z[f"step_post_progress_{k}"]
+        assert_bits_equal(st.random, z[f"step_post_random_{k}"], f"iteration {k}: random")
+        assert_bits_equal(st.progress[:, 0:2], post[:, 0:2], f"iteration {k}: counters")
+        close(st.progress[:, 4:7].view(np.float32), post[:, 4:7].view(np.float32), f"iteration {k}: mask")
+        close(st.progress[:, 8:11].view(np.float32), post[:, 8:11].view(np.float32), f"iteration {k}: accumulated colour")
+        close(st.rays, z[f"step_post_rays_{k}"], f"iteration {k}: rays")
+        close(st.out_tex, z[f"step_post_out_tex_{k}"], f"iteration {k}: out_tex")
+        finished = max(finished, int(z[f"step_post_out_tex_{k}"][:, 3].max()))
+    assert finished >= 2

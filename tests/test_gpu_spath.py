@@ -367,3 +367,28 @@ def test_primary_visibility_matches_the_reference_stored_render(rt, orc):
     check_against_stored_render(sc, g["source_results"], emitter, objects)
     st = oracle_spath_run(orc, sc, orc.KdTree(sc.verts4, sc.idx4), w, h, 1, 0)
     hits_equal(g["source_results"], st.source_results, "primary hits")
+
+
+def test_traversal_against_frozen_outputs_of_the_reference_kernel(rt):
+    """tests/golden/refkernel_ico4.npz: 22,464 rays and the hit records the REFERENCE's own kdtree_intersection
+    (compiled unmodified for gfx950, run on an MI355X; make_refkernel_fixture.py) returned for them.  The library's
+    traversal, through the C API, returns the same records bit for bit.  Needs nothing of the reference at run time."""
+    import ctypes as C
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "refkernel_ico4.npz"))
+    rays, want = np.ascontiguousarray(z["rays"]), z["hits"]
+    n = rays.shape[0]
+    sc = rt.scenes.icosphere_scene(4)
+    r = rt.Renderer(sc, 8, 8).build()
+    r.L.raytracer_prepass(r.rctx)
+    ro = r.L.rt_mem_alloc(r.dev, 16 * n); rd = r.L.rt_mem_alloc(r.dev, 16 * n); hits = r.L.rt_mem_alloc(r.dev, 16 * n)
+    r.upload(ro, np.ascontiguousarray(rays[:, 0:4])); r.upload(rd, np.ascontiguousarray(rays[:, 4:8]))
+    r.L.rt_k_kd_intersect(r.dev, C.byref(r.kdt.view), ro, rd, hits, n)
+    r.sync()
+    got = r.download(hits, np.uint32, 4 * n).reshape(n, 4)
+    assert_bits_equal(got[:, 0], want["tri"], "index offset")
+    for k, f in ((1, "t"), (2, "u"), (3, "v")):
+        assert_bits_equal(got[:, k], want[f].view(np.uint32), f)
+    for m in (ro, rd, hits):
+        r.L.rt_mem_free(r.dev, m)
+    r.close()
