@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Writes refkernel_ico4.npz: inputs and outputs of the REFERENCE's own kernels, run on an MI355X.
+"""Writes refkernel_ico4.npz and refkernel_brute.npz: inputs and outputs of the REFERENCE's own kernels, run on an
+MI355X.
 
 Needs a GPU box and oracle/_ref/refcl_ico4_strict.hsaco (the reference's OpenCL C kernel files compiled, unmodified,
 for gfx950 by oracle/build_ref_kernels.py where the reference checkout is mounted; flavour "strict": no contraction,
@@ -83,11 +84,34 @@ def main():
     out["rays"] = np.concatenate(ray_sets)
     out["hits"] = np.concatenate(hit_sets)
 
+    brute_force_fixture()
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     path = os.path.join(ROOT, "gpurun_out", "refkernel_ico4.npz")
     np.savez_compressed(path, **out)
     print("written", path, os.path.getsize(path), "bytes;", out["rays"].shape[0], "rays,",
           int((out["hits"]["t"] != 0).sum()), "hits")
+
+
+def brute_force_fixture():
+    """refkernel_brute.npz: cast_ray_test on the sphere + plane scene (128x128) and on the mixed scene (96x64), and
+    the first path_trace launch on the mixed scene, from the reference's kernels (flavour strict); the rays going in
+    are the oracle's generate_rays output."""
+    out = {}
+    for tag, sc, w, h in (("spheres", scenes.sphere_plane_scene(), 128, 128), ("mixed2", scenes.mixed_scene(2), 96, 64)):
+        tree = oracle.KdTree(sc.verts4, sc.idx4) if sc.idx4.shape[0] else None
+        rs = refcl.RefScene(refcl.RefProgram(tag, "strict"), sc, tree.blob if tree is not None else None)
+        rays = oracle.generate_rays(w, h)
+        d_rays, img = refcl.DevBuf.of(rays), refcl.DevBuf.zeros(4 * w * h)
+        rs.cast_ray_test(img, d_rays, w, h)
+        out[f"{tag}_size"] = np.array([w, h])
+        out[f"{tag}_cast_ray_test"] = img.read(np.uint32, w * h)
+        if tag == "mixed2":
+            fresh = refcl.DevBuf.zeros(16 * w * h)
+            rs.path_trace(fresh, d_rays, w, h, (0.0, 0.0, 0.0), 1)
+            out["mixed2_path_trace_first"] = fresh.read(np.float32, 4 * w * h).reshape(-1, 4)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    np.savez_compressed(os.path.join(ROOT, "gpurun_out", "refkernel_brute.npz"), **out)
+    print("written gpurun_out/refkernel_brute.npz")
 
 
 if __name__ == "__main__":

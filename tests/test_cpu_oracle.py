@@ -279,3 +279,23 @@ def test_oracle_against_outputs_of_the_reference_kernels(rt, orc):
         close(st.out_tex, z[f"step_post_out_tex_{k}"], f"iteration {k}: out_tex")
         finished = max(finished, int(z[f"step_post_out_tex_{k}"][:, 3].max()))
     assert finished >= 2
+
+
+def test_brute_force_integrators_against_outputs_of_the_reference_kernels(rt, orc):
+    """tests/golden/refkernel_brute.npz: cast_ray_test images and a first path_trace launch from the REFERENCE's own
+    kernels on an MI355X (make_refkernel_fixture.py).  Those kernels go through the built-ins normalize, sqrt, pow
+    and sin of ROCm's OpenCL library, so silhouette / shadow-edge pixels may fall the other way: stated tolerance
+    99.5 % of the packed pixels equal for cast_ray_test, 99 % of the pixels within 1e-4 for path_trace."""
+    z = np.load(os.path.join(GOLDEN, "refkernel_brute.npz"))
+    for tag, sc in (("spheres", rt.scenes.sphere_plane_scene()), ("mixed2", rt.scenes.mixed_scene(2))):
+        w, h = (int(v) for v in z[f"{tag}_size"])
+        rays = orc.generate_rays(w, h)
+        got = orc.cast_ray_test(sc, rays)
+        want = z[f"{tag}_cast_ray_test"]
+        assert (got == want).mean() >= 0.995, f"{tag}: {(got == want).mean():.4f} of pixels equal"
+        assert len(np.unique(want)) > 20
+        if tag == "mixed2":
+            fresh = orc.path_trace(sc, rays, w, h, (0, 0, 0), 1)
+            want = z["mixed2_path_trace_first"]
+            assert (np.abs(fresh - want).max(axis=1) < 1e-4).mean() >= 0.99
+            assert float(np.sqrt(np.mean((fresh - want) ** 2))) < 1e-2
