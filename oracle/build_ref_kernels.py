@@ -71,6 +71,7 @@ def scene_specs():
         "mixed2": scenes.mixed_scene(2),
         "spheres": scenes.sphere_plane_scene(),
         "path_obj2": path_obj2,
+        "ico8": scenes.icosphere_scene(8),          # the million-triangle benchmark scene (timing runs only)
     }
 
 
@@ -78,8 +79,13 @@ def scene_macros(sc) -> dict:
     """The prelude of src/raytracer.c:38-70 for one scene."""
     import oracle
     if sc.idx4.shape[0]:
-        tree = oracle.KdTree(sc.verts4, sc.idx4)
-        lo, hi = tree.bounds_min, tree.bounds_max
+        # kdt->bounds is the box of all triangle corners (src/kdtree.c:375-400); for the large scene it is taken
+        # from the arrays directly instead of through a single-threaded tree build
+        used = sc.verts4[np.unique(sc.idx4[:, 0]), :3]
+        lo, hi = used.min(axis=0), used.max(axis=0)
+        if sc.idx4.shape[0] < 600_000:
+            tree = oracle.KdTree(sc.verts4, sc.idx4)
+            assert np.array_equal(lo, tree.bounds_min) and np.array_equal(hi, tree.bounds_max)
     else:
         lo = hi = np.zeros(3, np.float32)
     return {
