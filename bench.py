@@ -14,8 +14,10 @@ gathered to rank 0 over RCCL at the end of the timed region; total work is
 fixed, so the scaling is strong.
 
 Rank 0 prints ONE JSON line: Mrays/s of the whole job, the HBM roofline figure
-of the dominant kernel (algorithmic bytes per launch / measured launch time)
-and a CPU baseline (the oracle restatement on a bounded sample, host cores).
+of the dominant kernel (algorithmic bytes per launch / measured launch time),
+a CPU baseline (the oracle restatement on a bounded sample, host cores) and,
+where the reference's own kernels have been compiled for gfx950 (oracle/_ref),
+their rate on this GPU on a few iterations of the same workload.
 """
 from __future__ import annotations
 
@@ -84,6 +86,51 @@ def cpu_baseline(rt, sc, r, width, full_height, threads, budget_s=12.0, max_iter
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
             "sample": f"iterations 2..{done + 1} of the same {width}x{full_height} workload "
                       f"({rays} rays, {dt:.1f} s), oracle/oracle_rt.c with OpenMP on {threads} threads"}
+
+
+def reference_kernels_same_gpu(sc, r, workload, width, height, threads, iters=8, groups=8192):
+    """The reference's own OpenCL C kernels (compiled from its sources for gfx950 into oracle/_ref/ where the
+    reference checkout was mounted, launched by the test harness in oracle/refcl.py) on this GPU, on the same frame,
+    scene, tree and RNG streams: a reported baseline like the CPU one, measured after the timed region.  Their
+    traversal has an unchecked 16-entry stack, so before each launch the oracle checks the rays and the few that
+    would overflow are replaced by null rays.  None where the code objects are not there."""
+    from oracle import refcl
+    import oracle
+    from raytracer_amd.scenes import splitmix32
+    tag = {"c3": "ico8", "c2": "ico6"}.get(workload)
+    if tag is None or not refcl.available(tag, "default"):
+        return None
+    kdt = r.kdt
+    blob = np.ctypeslib.as_array(kdt.buffer, shape=(int(kdt.buffer_size),)).copy()
+    tree = oracle.KdTree.from_blob(blob, sc.verts4, sc.idx4, kdt.bounds.min[:3], kdt.bounds.max[:3])
+    rs = refcl.RefScene(refcl.RefProgram(tag, "default"), sc, blob)
+    g = refcl.RefSpath(rs, width, height)
+    n = width * height
+    rb = splitmix32(1, np.arange(n, dtype=np.uint64))
+    rv = splitmix32(2, np.arange(iters + 2, dtype=np.uint64))
+    g.prepass(rb, int(rv[0]))
+    nulled, ms = 0, []
+    for k in range(iters + 1):
+        rays = g.rays
+        deep = tree.ray_stack(rays, nthreads=threads) > 16
+        if deep.any():
+            rays[deep] = 0
+            g.d_rays.write(rays)
+            nulled += int(deep.sum())
+        x = rs.prog.launch("xorshift_batch", [g.d_random], n)
+        t = rs.kd_intersect(g.d_results, g.d_rays, n, groups=groups)
+        s_ = rs.prog.launch("segmented_path_trace",
+                            [g.d_out_tex, g.d_rays, g.d_origin_rays, g.d_results, g.d_source_results, g.d_progress,
+                             g.d_random, rs.materials, rs.meshes, rs.indices, rs.vertices, rs.normals, width,
+                             int(rv[k + 1])], n)
+        if k > 0:                       # the first iteration traces the wiped (null) rays
+            ms.append(x + t + s_)
+    per_iter = float(np.mean(ms))
+    return {"value": round(n / (per_iter * 1e-3) / 1e6, 1), "unit": "Mrays/s", "kind": "reference kernels, same GPU",
+            "ms_per_step": round(per_iter, 3),
+            "sample": f"iterations 2..{iters + 1} of the same {width}x{height} workload: xorshift_batch + kdtree_intersection "
+                      f"({groups} one-wave groups) + segmented_path_trace, built by ROCm's clang with OpenCL's default options; "
+                      f"{nulled} rays that needed more than the reference's 16 stack entries replaced by null rays"}
 
 
 def gather_stats(rt, sc, r, threads, sample=262_144):
@@ -285,6 +332,13 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(rt, sc, r, width, height, threads)
             out["cpu_baseline"]["value"] = round(out["cpu_baseline"]["value"], 3)
+            try:
+                ref = reference_kernels_same_gpu(sc, r, args.workload, width, height, threads)
+            except Exception as e:          # the harness' launcher must not cost the benchmark its line
+                log(f"[bench] reference kernels not timed: {e}")
+                ref = None
+            if ref is not None:
+                out["reference_gpu"] = ref
         os.write(json_fd, (json.dumps(out) + "\n").encode())
 
     if torch is not None:
