@@ -180,18 +180,20 @@ def test_traversal_reference_kernel_equals_oracle_and_library(orc, refcl, rt, ta
     r.close()
 
 
-def test_traversal_default_flavour_finds_the_same_triangles(orc, refcl, rt):
+@pytest.mark.parametrize("tag,w,h", [("ico4", 128, 128), ("ico6", 256, 256)])
+def test_traversal_default_flavour_finds_the_same_triangles(orc, refcl, rt, tag, w, h):
     """The flavour clBuildProgram(NULL options) gives (contraction allowed, 2.5-ulp division): hit records are no
     longer bit-equal to anything, but the triangle found is the same for all but grazing rays.  Stated tolerance:
     at most 1 ray in 10,000 finds another triangle."""
-    sc, tree, rs = _scene(rt, orc, refcl, "ico4", "default")
-    rays = _test_rays(orc, sc, tree, 128, 128, 12, 4)
+    sc, tree, rs = _scene(rt, orc, refcl, tag, "default")
+    rays = _test_rays(orc, sc, tree, w, h, 12, 4)
     n = rays.shape[0]
     d_hits = refcl.DevBuf.zeros(16 * n)
     rs.kd_intersect(d_hits, refcl.DevBuf.of(rays), n)
     got = d_hits.read(refcl.HIT_DT, n)
     want = tree.intersect(rays)
     other = int((got["tri"] != want["tri"]).sum())
+    print(f"{tag}: default flavour: {other} of {n} rays find another triangle")
     assert other <= n // 10000, f"{other} of {n} rays find another triangle"
 
 
