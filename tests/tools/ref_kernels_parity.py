@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""Configuration 2 at full size on the reference's own kernels and on the library: 81,920-triangle mesh scene,
-1024x1024, 64 samples x 4 bounces = 256 iterations, same RNG streams.
+"""A configuration at full size on the reference's own kernels and on the library, same RNG streams: c2 = the
+81,920-triangle mesh scene at 1024x1024 (64 samples x 4 bounces = 256 iterations), c3 = the 1,310,720-triangle
+scene at 2048x2048.
 
-    python tests/tools/ref_kernels_c2_parity.py [iterations] [flavour]
+    python tests/tools/ref_kernels_parity.py [iterations] [flavour] [c2|c3]
 
 The reference's kernels (oracle/_ref code objects, launched by oracle/refcl.py) run free, iteration by iteration;
 before each traversal launch the oracle checks every ray's stack depth and the few that would overflow the
@@ -30,12 +31,21 @@ from raytracer_amd import scenes    # noqa: E402
 def main():
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     flavour = sys.argv[2] if len(sys.argv) > 2 else "default"
-    w = h = 1024
-    n = w * h
+    workload = sys.argv[3] if len(sys.argv) > 3 else "c2"
     seed = 1
-    sc = scenes.icosphere_scene(6)
-    tree = oracle.KdTree(sc.verts4, sc.idx4)
-    rs = refcl.RefScene(refcl.RefProgram("ico6", flavour), sc, tree.blob)
+    if workload == "c3":
+        w = h = 2048
+        sc = scenes.icosphere_scene(8)
+        host = rt.HostKdTree(sc)                       # the library's builder: same tree, seconds instead of minutes
+        tree = oracle.KdTree.from_blob(host.blob, sc.verts4, sc.idx4, host.bounds_min, host.bounds_max)
+        tag, name = "ico8", "c3: 1,310,720 triangles, 2048x2048"
+    else:
+        w = h = 1024
+        sc = scenes.icosphere_scene(6)
+        tree = oracle.KdTree(sc.verts4, sc.idx4)
+        tag, name = "ico6", "c2: 81,920 triangles, 1024x1024"
+    n = w * h
+    rs = refcl.RefScene(refcl.RefProgram(tag, flavour), sc, tree.blob)
     g = refcl.RefSpath(rs, w, h)
     rb = scenes.splitmix32(seed, np.arange(n, dtype=np.uint64))
     rv = scenes.splitmix32(seed + 1, np.arange(iters + 1, dtype=np.uint64))
@@ -75,7 +85,7 @@ def main():
     d = np.abs(a - b).max(axis=1)
     ch = lambda x, s: ((x >> s) & 0xff).astype(np.int32)
     lv = np.max([np.abs(ch(ref_img8, s) - ch(lib_img8, s)) for s in (0, 8, 16)], axis=0)[keep]
-    out = {"workload": "c2: 81,920 triangles, 1024x1024", "iterations": iters, "flavour": flavour,
+    out = {"workload": name, "iterations": iters, "flavour": flavour,
            "pixels_left_out": int(touched.sum()),
            "radiance_rmse": float(np.sqrt(np.mean((a - b) ** 2))),
            "image_mean_ref": float(a.mean()), "image_mean_lib": float(b.mean()),
