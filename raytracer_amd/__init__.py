@@ -170,7 +170,7 @@ EXPORTED_SYMBOLS = [
     "rt_device_count", "rt_device_open", "rt_device_close", "rt_device_get_props", "rt_device_sync",
     "rt_device_stream", "rt_device_ordinal", "rt_device_select_stream", "rt_mem_alloc", "rt_mem_free", "rt_mem_upload", "rt_mem_download",
     "rt_mem_zero", "rt_mem_copy", "rt_event_record", "rt_event_elapsed_ms", "rt_event_release", "rt_timing_enable", "rt_timing_reset", "rt_timing_get", "rt_kernel_name",
-    "rt_k_generate_rays", "rt_k_kd_intersect", "rt_k_spath_init", "rt_k_spath_trace", "rt_k_xorshift",
+    "rt_k_generate_rays", "rt_k_kd_intersect", "rt_k_kd_intersect_noalloc", "rt_k_spath_init", "rt_k_spath_trace", "rt_k_xorshift",
     "rt_k_spath_run", "rt_k_pixel_order", "rt_k_resolve_avg", "rt_k_cast_rays", "rt_k_path_trace", "rt_k_f_buffer_average",
     "rt_k_f_to_byte",
     # loader.h
@@ -258,6 +258,8 @@ def lib():
     L.rt_obj_free.argtypes = [C.POINTER(rt_obj)]
     L.rt_k_generate_rays.argtypes = [vp, vp, vp, u32, u32, C.POINTER(rt_rows), C.c_float]
     L.rt_k_kd_intersect.argtypes = [vp, C.POINTER(rt_kd_view), vp, vp, vp, u32]
+    L.rt_k_kd_intersect_noalloc.restype = C.c_int
+    L.rt_k_kd_intersect_noalloc.argtypes = [vp, C.POINTER(rt_kd_view), vp, vp, vp, u32]
     L.rt_k_spath_init.argtypes = [vp, C.POINTER(rt_kd_view), C.POINTER(rt_spath_buffers), u32, u32, C.POINTER(rt_rows), u32]
     L.rt_k_spath_trace.argtypes = [vp, C.POINTER(rt_kd_view), C.POINTER(rt_spath_buffers), u32, u32, C.c_int]
     L.rt_k_xorshift.argtypes = [vp, vp, u32]

@@ -38,6 +38,7 @@ rt_device *rt_device_open(int ordinal)
     dev->stream = dev->streams[0];
     RT_HIP_CHECK(hipMalloc((void **)&dev->counters, 64 * RT_MAX_STREAMS));
     RT_HIP_CHECK(hipMemset(dev->counters, 0, 64 * RT_MAX_STREAMS));
+    rt_kernels_setup_device(dev);
     return dev;
 }
 

@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <map>
 #include <vector>
 
 #include "rt_hip.h"
@@ -38,7 +39,15 @@ struct rt_device {
     rt_timing_slot slots[RT_K_COUNT];
     std::vector<hipEvent_t> free_events;
     uint32_t *counters = nullptr;   // device words the kernels use as work counters: one 64-byte line per stream
+    // This GPU's copy of the kernels' file-scope scratch array (work counters of the entry point that allocates
+    // nothing), resolved once by rt_kernels_setup_device, and that entry point's launch geometry.
+    uint32_t *static_counters = nullptr;
+    int noalloc_blocks_per_cu = 0;
+    std::map<const void *, int> blocks_per_cu;   // resident one-wave blocks per CU of each persistent kernel on this device
 };
+
+// Per-device set-up of the kernel translation unit (called by rt_device_open with the device current).
+void rt_kernels_setup_device(rt_device *dev);
 
 // Brackets one launch with events when timing is on.
 struct rt_launch_timer {

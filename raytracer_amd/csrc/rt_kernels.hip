@@ -1152,6 +1152,22 @@ void check_kd(const rt_kd_view *kd, const char *who)
     }
 }
 
+// Resident one-wave blocks per CU of a persistent kernel on this device (asked of the runtime once per device
+// and kernel: two devices of one process may differ).
+template <typename K>
+int resident_blocks_per_cu(rt_device *dev, K kern)
+{
+    const void *key = (const void *)kern;
+    auto it = dev->blocks_per_cu.find(key);
+    if (it != dev->blocks_per_cu.end()) return it->second;
+    int b = 0;
+    RT_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, kern, 64, 0));
+    if (b < 1) b = 1;
+    if (getenv("RT_VERBOSE")) fprintf(stderr, "[rt] device %d: persistent kernel %p keeps %d waves per CU\n", dev->ordinal, key, b);
+    dev->blocks_per_cu[key] = b;
+    return b;
+}
+
 // Launch geometry of the persistent traversal kernel: as many one-wave blocks
 // as the chip keeps resident for this kernel (LDS-limited), never more than
 // there are 64-ray groups.  RT_TRAVERSE_VARIANT (environment, read once)
@@ -1160,11 +1176,8 @@ template <int LDS_DEPTH, int REFILL_MIN, int CHUNK>
 void launch_kd_variant(rt_device *dev, const TravScene &P, const float4 *ro, const float4 *rd, Hit *hits, uint32_t n)
 {
     auto kern = k_kd_intersect<LDS_DEPTH, REFILL_MIN, CHUNK>;
-    static int blocks_per_cu = 0;
-    if (!blocks_per_cu) {
-        RT_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kern, 64, 0));
-        if (blocks_per_cu < 1) blocks_per_cu = 1;
-    }
+    RT_HIP_CHECK(hipSetDevice(dev->ordinal));
+    const int blocks_per_cu = resident_blocks_per_cu(dev, kern);
     static int waves_per_cu = -1;
     if (waves_per_cu < 0) {
         const char *e = getenv("RT_TRAVERSE_WAVES_PER_CU");
@@ -1201,14 +1214,10 @@ void launch_run_variant(rt_device *dev, const TravScene &P, const SpathDev &B, u
                         const uint32_t *rv)
 {
     auto kern = k_spath_run<LDS_DEPTH, SHADE_MIN, CHUNK, NI, NT, WAVES>;
-    static int blocks_per_cu = 0;
-    if (!blocks_per_cu) {
-        RT_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kern, 64, 0));
-        if (blocks_per_cu < 1) blocks_per_cu = 1;
-        const char *cap = getenv("RT_WAVES_PER_CU");      // tuning: fewer resident waves than would fit
-        if (cap && atoi(cap) > 0 && atoi(cap) < blocks_per_cu) blocks_per_cu = atoi(cap);
-        if (getenv("RT_VERBOSE")) fprintf(stderr, "[rt] render kernel: %d waves per CU\n", blocks_per_cu);
-    }
+    RT_HIP_CHECK(hipSetDevice(dev->ordinal));
+    int blocks_per_cu = resident_blocks_per_cu(dev, kern);
+    const char *cap = getenv("RT_WAVES_PER_CU");      // tuning: fewer resident waves than would fit
+    if (cap && atoi(cap) > 0 && atoi(cap) < blocks_per_cu) blocks_per_cu = atoi(cap);
     unsigned grid = (unsigned)blocks_per_cu * (unsigned)dev->props.multiProcessorCount;
     const unsigned need = blocks_for(n, 64);
     if (grid > need) grid = need;
@@ -1264,6 +1273,30 @@ void launch_spath_run(rt_device *dev, const TravScene &P, const SpathDev &B, uin
 
 #define RT_AFTER_LAUNCH() RT_HIP_CHECK(hipGetLastError())
 
+// ---------------------------------------------------------------------------
+// Scratch memory of rt_k_kd_intersect_noalloc: the work counters its persistent
+// waves claim rays from, one 64-byte line per stream of an rt_device.  The array
+// lives in the code object, so every GPU the library runs on holds its own copy
+// (512 bytes) at its own address until the process ends.  In host code the name
+// `scratch` is only a handle for hipGetSymbolAddress -- it is not a device
+// address and is never passed to a kernel, a memset or a copy: set-up resolves
+// it once per device into rt_device::static_counters and everything uses that.
+// ---------------------------------------------------------------------------
+#define RT_NOALLOC_SCRATCH_WORDS (16 * RT_MAX_STREAMS)
+static __device__ __align__(256) uint32_t scratch[RT_NOALLOC_SCRATCH_WORDS];
+
+void rt_kernels_setup_device(rt_device *dev)
+{
+    // the caller (rt_device_open) has made dev->ordinal the current device
+    void *p = nullptr;
+    RT_HIP_CHECK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    dev->static_counters = (uint32_t *)p;
+    RT_HIP_CHECK(hipMemset(dev->static_counters, 0, sizeof(uint32_t) * RT_NOALLOC_SCRATCH_WORDS));
+    // the launch geometry is asked for here so that the entry point itself calls nothing that may load or allocate
+    RT_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&dev->noalloc_blocks_per_cu, k_kd_intersect<12, 16, 256>, 64, 0));
+    if (dev->noalloc_blocks_per_cu < 1) dev->noalloc_blocks_per_cu = 1;
+}
+
 extern "C" {
 
 // The kernels index frame rows without bounds of their own: refuse a mapping
@@ -1306,6 +1339,37 @@ void rt_k_kd_intersect(rt_device *dev, const rt_kd_view *kd, rt_mem ray_o, rt_me
     P.smax = host3(kd->scene_max);
     P.root_ref = kd->root_ref;
     launch_kd_intersect(dev, P, (const float4 *)ray_o, (const float4 *)ray_d, (Hit *)hits, n);
+}
+
+int rt_k_kd_intersect_noalloc(rt_device *dev, const rt_kd_view *kd, rt_mem ray_o, rt_mem ray_d, rt_mem hits, uint32_t n)
+{
+    if (!n) return 0;
+    if (n > RT_NOALLOC_MAX_RAYS) {
+        fprintf(stderr, "ERROR: rt_k_kd_intersect_noalloc: %u rays in one call, the limit is %u "
+                        "(the 32-bit work counter is claimed in chunks past the end)\n", n, (unsigned)RT_NOALLOC_MAX_RAYS);
+        return 1;
+    }
+    if (!kd || !kd->nodes || !kd->leaf_tris || kd->num_leaf_slots == 0 || !ray_o || !ray_d || !hits || !dev->static_counters) {
+        fprintf(stderr, "ERROR: rt_k_kd_intersect_noalloc: no flattened kd-tree, or a null ray / hit buffer\n");
+        return 2;
+    }
+    TravScene P;
+    P.nodes = (const uint4 *)kd->nodes;
+    P.leaf_tris = (const float4 *)kd->leaf_tris;
+    P.smin = host3(kd->scene_min);
+    P.smax = host3(kd->scene_max);
+    P.root_ref = kd->root_ref;
+    RT_HIP_CHECK(hipSetDevice(dev->ordinal));
+    unsigned grid = (unsigned)dev->noalloc_blocks_per_cu * (unsigned)dev->props.multiProcessorCount;
+    const unsigned need = blocks_for(n, 64);
+    if (grid > need) grid = need;
+    // the array keeps the last call's count: clear this stream's line, in stream order, before the launch
+    uint32_t *counter = dev->static_counters + 16 * dev->current;
+    RT_HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(uint32_t), dev->stream));
+    hipLaunchKernelGGL((k_kd_intersect<12, 16, 256>), dim3(grid), dim3(64), 0, dev->stream, P, (const float4 *)ray_o,
+                       (const float4 *)ray_d, (Hit *)hits, n, counter);
+    RT_HIP_CHECK(hipGetLastError());
+    return 0;
 }
 
 void rt_k_spath_init(rt_device *dev, const rt_kd_view *kd, const rt_spath_buffers *b, uint32_t w, uint32_t h,
