@@ -7,8 +7,11 @@ A step is one render iteration (spath_raytracer_render): one bounce of every
 pixel's path = one ray per pixel traced through the kd-tree and shaded.  The
 default workload is the million-triangle configuration the headline metric is
 quoted on: a 1,310,720-triangle displaced icosphere in a room with an emissive
-quad ("c3"), 2048x2048 pixels.  With N > 1 (one process per GPU, launched by
-torch.distributed.run) the frame's rows are dealt to the ranks in bands of 8,
+quad ("c3"), 2048x2048 pixels.  With N > 1 there is one process per GPU: started
+by torch.distributed.run (RANK / WORLD_SIZE in the environment), or, when this
+script is run plainly with --gpus N, by this script itself, which then starts
+that launcher as a child process before anything has touched a GPU and hands
+its output and exit code on.  The frame's rows are dealt to the ranks in bands of 8,
 each rank renders its rows with the scene replicated, and the resolved rows are
 gathered to rank 0 over RCCL at the end of the timed region; total work is
 fixed, so the scaling is strong.
@@ -57,7 +60,30 @@ def make_scene(spec):
     return scenes.soup_scene(arg)
 
 
-def cpu_baseline(rt, sc, r, width, full_height, threads, budget_s=12.0, max_iters=96):
+def host_cpu():
+    """(threads to use, description).  The job's share of the host is what the scheduler gives it
+    (OMP_NUM_THREADS / the affinity mask), which on a shared GPU host is less than the machine."""
+    model = "unknown CPU"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    nproc = os.cpu_count() or 1
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        affinity = nproc
+    share = affinity
+    env = os.environ.get("OMP_NUM_THREADS", "")
+    if env.isdigit() and int(env) > 0:
+        share = min(share, int(env))
+    return share, f"{model}; nproc {nproc}, affinity {affinity}, OMP_NUM_THREADS {env or 'unset'}"
+
+
+def cpu_baseline(rt, sc, r, width, full_height, threads, cpu_desc, budget_s=12.0, max_iters=96):
     """Oracle (C restatement, OpenMP) on a bounded sample of the same workload:
     the same frame, scene and RNG streams, prepass and the first (null-ray)
     iteration untimed, then whole iterations until about `budget_s` seconds of
@@ -85,7 +111,8 @@ def cpu_baseline(rt, sc, r, width, full_height, threads, budget_s=12.0, max_iter
     rays = width * full_height * done
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
             "sample": f"iterations 2..{done + 1} of the same {width}x{full_height} workload "
-                      f"({rays} rays, {dt:.1f} s), oracle/oracle_rt.c with OpenMP on {threads} threads"}
+                      f"({rays} rays, {dt:.1f} s), oracle/oracle_rt.c with OpenMP on {threads} threads "
+                      f"(all of this job's share of the host: {cpu_desc})"}
 
 
 def reference_kernels_same_gpu(sc, r, workload, width, height, threads, iters=8, groups=8192):
@@ -155,21 +182,45 @@ def gather_stats(rt, sc, r, threads, sample=262_144):
     return per_ray, b_gather
 
 
+def spawn_ranks(n):
+    """Plain `python bench.py --gpus N`: start N ranks with torch's launcher as a child process and hand on its
+    output and exit code.  Nothing in this process has initialised a GPU (counting devices does not)."""
+    import socket
+    import subprocess
+    if not os.environ.get("RT_BENCH_SHARE_GPU"):
+        import torch
+        have = torch.cuda.device_count()
+        if have < n:
+            log(f"bench.py: --gpus {n} but {have} GPU(s) are visible")
+            return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--workload", default=os.environ.get("RT_BENCH_WORKLOAD", "c3"), choices=sorted(WORKLOADS))
     ap.add_argument("--separate-kernels", action="store_true", help="three launches per iteration, as the reference")
     ap.add_argument("--max-batch", type=int, default=None, help="most iterations folded into one launch")
     ap.add_argument("--no-reorder", action="store_true", help="serve pixels in index order in every batch")
     ap.add_argument("--schedule", type=int, default=None, choices=[0, 1, 2],
-                    help="fix the kernel's slot schedule (default: the library times them on its first batch)")
+                    help="fix the kernel's slot schedule (default: the library's prepass times them)")
+    ap.add_argument("--no-run-ahead", action="store_true", help="launches hold only iterations already asked for "
+                    "(they then end at every resolve point, every 50 iterations)")
     ap.add_argument("--size", type=int, default=0, help="override the workload's frame: SIZE x SIZE pixels (tuning runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
 
     # The library reports scene/tree progress on stdout like the reference does;
     # keep stdout for the one JSON line and send everything else to stderr.
@@ -180,8 +231,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        log(f"note: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
     n_gpus = world
 
     # RT_BENCH_FORCE_DIST=1 takes the multi-process path with a single rank, RT_BENCH_BACKEND=gloo and
@@ -222,7 +273,9 @@ def main():
     r.build()
     t_build = time.perf_counter() - t0
     r.init_spath(seed=1, separate_kernels=args.separate_kernels, resolve_interval=50, quiet=True,
-                 max_batch=args.max_batch, reorder=not args.no_reorder, schedule=args.schedule)
+                 max_batch=args.max_batch, reorder=not args.no_reorder, schedule=args.schedule,
+                 run_ahead=not args.no_run_ahead)
+    # the prepass ends with the library's calibration of the kernel's slot schedules (untimed, like the tree build)
     r.spath_prepass(num_iterations=1 << 30)
     if rank == 0:
         log(f"[bench] {desc}: {sc.num_tris} triangles, scene {t_scene:.1f}s, build {t_build:.1f}s, "
@@ -234,19 +287,19 @@ def main():
             torch.cuda.synchronize()
             dist.barrier()
 
-    r.spath_render(args.warmup)
-    sync_all()
     if torch is not None and args.schedule is None and not args.separate_kernels:
-        # Every rank timed the kernel's slot schedules on its own share during the warm-up; the shares are
+        # Every rank timed the kernel's slot schedules on its own share in its prepass; the shares are
         # interleaved bands of one picture, so they should agree, and a rank that a noisy timing sent the other
         # way would set the job's time.  All ranks take the choice most of them made (results do not depend on it).
-        r.L.spath_raytracer_flush(r.spath)          # reads the trial's timings if they are still pending
-        r.sync()
         mine = torch.zeros(3, dtype=torch.int64, device=f"cuda:{local_rank}" if backend == "nccl" else "cpu")
         mine[int(r.spath.contents.schedule)] = 1
         dist.all_reduce(mine)
         r.spath.contents.schedule = int(torch.argmax(mine).item())
         r.spath.contents.schedule_fixed = 1
+    # Renderer.spath_render ends the render where its calls end while they run, so the library's launches never
+    # reach past the warm-up into the timed iterations, nor past those
+    r.spath_render(args.warmup)
+    sync_all()
     r.timing(True)
     r.timing_reset()
 
@@ -297,7 +350,8 @@ def main():
     if rank == 0:
         total_rays = width * height * args.steps
         value = total_rays / dt / 1e6
-        threads = args.cpu_threads or min(16, os.cpu_count() or 1)
+        threads, cpu_desc = host_cpu()
+        threads = args.cpu_threads or threads
         per_ray, b_gather = gather_stats(rt, sc, r, threads)
         b_ray = B_STREAM + b_gather
         avg_ms = kms / max(launches, 1)
@@ -319,7 +373,10 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {desc}", "triangles": int(sc.num_tris), "width": width,
                        "height": height, "rows_per_gpu": strip, "kernel": kname,
-                       "schedule": int(r.spath.contents.schedule), "frame_crc32": f"{frame_crc:08x}",
+                       "schedule": int(r.spath.contents.schedule),
+                       "schedule_calibration_ms_per_iteration": [round(float(x), 4) for x in r.spath.contents.trial_ms]
+                       if int(r.spath.contents.trial_state) == 2 else None,
+                       "run_ahead": not args.no_run_ahead, "frame_crc32": f"{frame_crc:08x}",
                        "partition": f"{BAND_ROWS}-row bands dealt to {world} ranks + RCCL gather of the resolved frame" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
@@ -330,7 +387,7 @@ def main():
                          "per_ray": {k: round(v, 3) for k, v in per_ray.items()}},
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(rt, sc, r, width, height, threads)
+            out["cpu_baseline"] = cpu_baseline(rt, sc, r, width, height, threads, cpu_desc)
             out["cpu_baseline"]["value"] = round(out["cpu_baseline"]["value"], 3)
             try:
                 ref = reference_kernels_same_gpu(sc, r, args.workload, width, height, threads)

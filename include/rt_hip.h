@@ -214,8 +214,19 @@ void rt_k_xorshift(rt_device *dev, rt_mem random, uint32_t n);
                                           (or a rank's share of it) has too few pixels to keep every lane busy, a batch
                                           lasts as long as its heaviest pixel's chain of steps, and this shortens it */
 #define RT_SCHEDULE_COUNT          3
+#define RT_RUN_MAX_ITERS     1024u  /* iterations per launch */
+#define RT_RUN_MAX_SNAPSHOTS 32u
 void rt_k_spath_run(rt_device *dev, const rt_kd_view *kd, const rt_spath_buffers *b, uint32_t n, uint32_t iters,
                     rt_mem random_values, rt_mem cost, rt_mem order, int schedule);
+
+/* rt_k_spath_run for a launch that spans points at which the reference resolves its frame
+   (src/spath_raytracer.c:389-390): after the snap_first-th iteration of the launch and then after every
+   snap_every-th, each pixel's out_tex entry is copied to snapshots[slot * n + pixel], slot = 0, 1, ... --
+   what out_tex would hold had the launch ended there; rt_k_resolve_avg on a slot gives the frame of that
+   iteration.  snapshots == NULL or snap_first == 0: none.  At most RT_RUN_MAX_SNAPSHOTS slots. */
+void rt_k_spath_run_snap(rt_device *dev, const rt_kd_view *kd, const rt_spath_buffers *b, uint32_t n, uint32_t iters,
+                         rt_mem random_values, rt_mem cost, rt_mem order, int schedule, rt_mem snapshots,
+                         uint32_t snap_first, uint32_t snap_every);
 
 /* The order in which the next rt_k_spath_run hands pixels to lanes: heaviest
    first, by cost >> shift (counting sort, 256 buckets), into order[0..n);

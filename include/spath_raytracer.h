@@ -18,7 +18,7 @@ enum {
                              value of launch k = splitmix32(rng_seed + 1, k); reproducible */
 };
 
-#define RT_TRIAL_PARTS 4   /* launches of a schedule trial: default, two alternatives, default */
+#define RT_TRIAL_PARTS 4   /* timed launches of a calibration: default schedule, two alternatives, default */
 
 typedef struct spath_raytracer_context {
     struct _rt_ctx *rctx;
@@ -50,9 +50,10 @@ typedef struct spath_raytracer_context {
     int          separate_kernels;    /* 1: three launches per iteration, as the reference; 0: iterations are batched
                                          into multi-iteration launches (rt_k_spath_run) */
     bool         quiet;
-    unsigned int max_batch;           /* most iterations folded into one launch (0 = 64); a batch always ends at a resolve point */
+    unsigned int max_batch;           /* most iterations folded into one launch; 0 = four resolve intervals (64 when
+                                         resolve_interval is 0), at most RT_RUN_MAX_ITERS */
     unsigned int pending;             /* iterations accepted by spath_raytracer_render but not launched yet */
-    unsigned int *pending_values;     /* their random values */
+    unsigned int *pending_values;     /* random values of the iterations of the launch being put together */
     rt_mem       cl_random_value_buffer;
     rt_mem       cl_pixel_cost_buffer;   /* walk steps per pixel in the last batch */
     rt_mem       cl_pixel_order_buffer;  /* pixels by decreasing cost: service order of the next batch */
@@ -61,13 +62,28 @@ typedef struct spath_raytracer_context {
     bool         order_valid;
     int          no_reorder;             /* 1: always serve pixels in index order */
     int          schedule;               /* RT_SCHEDULE_* the batches run with */
-    int          schedule_fixed;         /* 1: keep `schedule`; 0: the first batch of a render that is long enough is
-                                            split in RT_TRIAL_PARTS launches (default schedule, the alternatives,
-                                            default again), and an alternative is kept if it beats both default runs
-                                            by 5 % */
-    int          trial_state;            /* 0: not tried yet, 1: trial queued, 2: decided */
-    rt_event     trial_marks[RT_TRIAL_PARTS + 1];
-    unsigned int trial_iters[RT_TRIAL_PARTS];
+    int          schedule_fixed;         /* 1: keep `schedule`; 0: spath_raytracer_prepass ends with
+                                            spath_raytracer_calibrate, which times the schedules on this scene and frame */
+    int          trial_state;            /* 0: not calibrated yet, 2: decided (kept for later renders of this context) */
+    float        trial_ms[RT_TRIAL_PARTS];   /* ms per iteration of the calibration's launches: default schedule, the
+                                                two alternatives, default again */
+    unsigned int calibration_iterations; /* iterations per calibration launch (0 = 12) */
+
+    /* Launches that run ahead of the caller.  A pixel's iterations depend on nothing but the pixel, the iteration
+       number and the random streams, and the caller sees the device's state only through output_buffer at the
+       resolve points, so the render call that finds its iteration not launched yet launches it together with the
+       following ones (up to max_batch, never past num_iterations) in ONE launch; the calls for those iterations then
+       find their work done.  Where such a launch crosses a resolve point the kernel keeps a copy of each pixel's
+       accumulator as it stood after that iteration, and the frame handed to the caller there is resolved from the
+       copy: the same bits, at the same call, as with one launch per iteration.  Without it every launch ends in a
+       stretch where the GPU only finishes its slowest pixels; longer launches have fewer of those. */
+    int          run_ahead;              /* 1 (default): as above; 0: a launch holds only iterations the caller has asked for */
+    unsigned int launched_upto;          /* iterations launched so far (>= current_iteration when running ahead) */
+    rt_mem       cl_snapshot_buffer;     /* [slot][pixel] float4: out_tex at the resolve points of the last launch */
+    unsigned int snapshot_slots;         /* slots allocated */
+    unsigned int snap_first_iteration;   /* iteration whose accumulator slot 0 holds (0: the last launch took none) */
+    unsigned int snap_count;
+    unsigned int launches;               /* rt_k_spath_run launches since the prepass (diagnostic) */
 } spath_raytracer_context;
 
 spath_raytracer_context *init_spath_raytracer_context(struct _rt_ctx *rctx);   /* src/spath_raytracer.c:39-116 */
@@ -76,7 +92,15 @@ void spath_raytracer_prepass(spath_raytracer_context *ctx);                     
 
 /* not in the reference */
 void spath_raytracer_flush(spath_raytracer_context *ctx);     /* launch whatever render calls are still pending */
-void spath_raytracer_resolve(spath_raytracer_context *ctx);   /* flush, resolve + blocking readback into output_buffer */
+void spath_raytracer_resolve(spath_raytracer_context *ctx);   /* flush, then resolve the accumulator as the device holds it
+                                                                  (with run_ahead that may be ahead of current_iteration)
+                                                                  + blocking readback into output_buffer */
+/* Times the kernel's slot schedules (RT_SCHEDULE_*) on this scene and frame and keeps the fastest in ctx->schedule.
+   Called by spath_raytracer_prepass when schedule_fixed is 0 and no decision exists yet; needs the state a prepass
+   leaves.  Runs a few throw-away iterations on the per-pixel buffers and puts them back exactly (copies taken
+   before), draws nothing from the random streams, and leaves the pixel order of the first real launch behind:
+   rendered results do not depend on it.  Frames under 65,536 pixels and separate_kernels mode keep the default. */
+void spath_raytracer_calibrate(spath_raytracer_context *ctx);
 void spath_raytracer_fill_buffers(spath_raytracer_context *ctx, rt_spath_buffers *out);
 void spath_raytracer_destroy(spath_raytracer_context *ctx);   /* the reference never releases its buffers */
 

@@ -140,7 +140,10 @@ class spath_raytracer_context(C.Structure):
                 ("cl_cost_hist_buffer", C.c_void_p), ("cl_tile_scratch_buffer", C.c_void_p),
                 ("order_valid", C.c_bool), ("no_reorder", C.c_int),
                 ("schedule", C.c_int), ("schedule_fixed", C.c_int), ("trial_state", C.c_int),
-                ("trial_marks", C.c_void_p * 5), ("trial_iters", C.c_uint * 4)]
+                ("trial_ms", C.c_float * 4), ("calibration_iterations", C.c_uint),
+                ("run_ahead", C.c_int), ("launched_upto", C.c_uint), ("cl_snapshot_buffer", C.c_void_p),
+                ("snapshot_slots", C.c_uint), ("snap_first_iteration", C.c_uint), ("snap_count", C.c_uint),
+                ("launches", C.c_uint)]
 
 
 class rt_device_props(C.Structure):
@@ -162,6 +165,8 @@ _ABI_OFFSETS = [("raytracer_context", "stat_scene"), ("raytracer_context", "rcl"
                 ("kd_tree", "build_threads"), ("spath_raytracer_context", "cl_random_buffer"),
                 ("spath_raytracer_context", "rng_mode"), ("spath_raytracer_context", "quiet"), ("spath_raytracer_context", "max_batch"),
                 ("spath_raytracer_context", "cl_random_value_buffer"), ("spath_raytracer_context", "no_reorder"),
+                ("spath_raytracer_context", "trial_ms"), ("spath_raytracer_context", "run_ahead"),
+                ("spath_raytracer_context", "cl_snapshot_buffer"), ("spath_raytracer_context", "launches"),
                 ("path_raytracer_context", "cl_path_output_buffer")]
 
 # every symbol the headers under include/ declare
@@ -171,7 +176,7 @@ EXPORTED_SYMBOLS = [
     "rt_device_stream", "rt_device_ordinal", "rt_device_select_stream", "rt_mem_alloc", "rt_mem_free", "rt_mem_upload", "rt_mem_download",
     "rt_mem_zero", "rt_mem_copy", "rt_event_record", "rt_event_elapsed_ms", "rt_event_release", "rt_timing_enable", "rt_timing_reset", "rt_timing_get", "rt_kernel_name",
     "rt_k_generate_rays", "rt_k_kd_intersect", "rt_k_kd_intersect_noalloc", "rt_k_spath_init", "rt_k_spath_trace", "rt_k_xorshift",
-    "rt_k_spath_run", "rt_k_pixel_order", "rt_k_resolve_avg", "rt_k_cast_rays", "rt_k_path_trace", "rt_k_f_buffer_average",
+    "rt_k_spath_run", "rt_k_spath_run_snap", "rt_k_pixel_order", "rt_k_resolve_avg", "rt_k_cast_rays", "rt_k_path_trace", "rt_k_f_buffer_average",
     "rt_k_f_to_byte",
     # loader.h
     "load_scene_json", "load_scene_json_url", "load_file", "rt_set_resource_root", "rt_obj_parse", "rt_obj_free",
@@ -196,7 +201,7 @@ EXPORTED_SYMBOLS = [
     "init_ss_raytracer_context", "ss_raytracer_render", "ss_raytracer_prepass",
     "init_path_raytracer_context", "path_raytracer_render", "path_raytracer_prepass",
     "init_spath_raytracer_context", "spath_raytracer_render", "spath_raytracer_prepass",
-    "spath_raytracer_resolve", "spath_raytracer_flush", "spath_raytracer_fill_buffers",
+    "spath_raytracer_resolve", "spath_raytracer_flush", "spath_raytracer_fill_buffers", "spath_raytracer_calibrate",
     "ss_raytracer_destroy", "path_raytracer_destroy", "spath_raytracer_destroy",
 ]
 
@@ -264,6 +269,8 @@ def lib():
     L.rt_k_spath_trace.argtypes = [vp, C.POINTER(rt_kd_view), C.POINTER(rt_spath_buffers), u32, u32, C.c_int]
     L.rt_k_xorshift.argtypes = [vp, vp, u32]
     L.rt_k_spath_run.argtypes = [vp, C.POINTER(rt_kd_view), C.POINTER(rt_spath_buffers), u32, u32, vp, vp, vp, C.c_int]
+    L.rt_k_spath_run_snap.argtypes = [vp, C.POINTER(rt_kd_view), C.POINTER(rt_spath_buffers), u32, u32, vp, vp, vp, C.c_int,
+                                      vp, u32, u32]
     L.rt_k_pixel_order.argtypes = [vp, vp, vp, vp, u32, u32, u32, vp]
     L.rt_k_resolve_avg.argtypes = [vp, vp, vp, u32]
     L.rt_k_f_buffer_average.argtypes = [vp, vp, vp, u32, u32]
@@ -297,7 +304,8 @@ def lib():
     L.path_raytracer_prepass.argtypes = [C.POINTER(path_raytracer_context)]
     L.init_spath_raytracer_context.restype = C.POINTER(spath_raytracer_context)
     L.init_spath_raytracer_context.argtypes = [C.POINTER(raytracer_context)]
-    for f in ("spath_raytracer_render", "spath_raytracer_prepass", "spath_raytracer_resolve", "spath_raytracer_flush"):
+    for f in ("spath_raytracer_render", "spath_raytracer_prepass", "spath_raytracer_resolve", "spath_raytracer_flush",
+              "spath_raytracer_calibrate"):
         getattr(L, f).argtypes = [C.POINTER(spath_raytracer_context)]
     L.spath_raytracer_fill_buffers.argtypes = [C.POINTER(spath_raytracer_context), C.POINTER(rt_spath_buffers)]
     L.spath_raytracer_destroy.argtypes = [C.POINTER(spath_raytracer_context)]
@@ -460,7 +468,8 @@ class Renderer:
         return self.scene.contents.kdt.contents
 
     def init_spath(self, seed: int = 1, separate_kernels: bool = False, resolve_interval: int = 50, quiet: bool = True,
-                   max_batch: int | None = None, reorder: bool = True, schedule: int | None = None):
+                   max_batch: int | None = None, reorder: bool = True, schedule: int | None = None,
+                   run_ahead: bool = True):
         if not self.built:
             self.build()
         self.spath = self.L.init_spath_raytracer_context(self.rctx)
@@ -473,7 +482,8 @@ class Renderer:
         if max_batch is not None:
             c.max_batch = max_batch
         c.no_reorder = 0 if reorder else 1
-        if schedule is not None:         # None: the library tries both on its first long batch
+        c.run_ahead = 1 if run_ahead else 0
+        if schedule is not None:         # None: the prepass ends with a calibration of the schedules
             c.schedule = schedule
             c.schedule_fixed = 1
         return self.spath
@@ -487,10 +497,19 @@ class Renderer:
         """`calls` render calls; by default the iterations still pending in the
         library's batch are launched before returning (not waited for)."""
         f = self.L.spath_raytracer_render
-        for _ in range(calls):
-            f(self.spath)
-        if flush:
-            self.L.spath_raytracer_flush(self.spath)
+        c = self.spath.contents
+        # The library may launch iterations ahead of the calls that ask for them, never past num_iterations:
+        # while these calls run, the render ends (at the latest) where they end, so that the device holds
+        # exactly the state after `calls` more iterations when they return.
+        total = int(c.num_iterations)
+        c.num_iterations = min(total, int(c.current_iteration) + calls)
+        try:
+            for _ in range(calls):
+                f(self.spath)
+            if flush:
+                self.L.spath_raytracer_flush(self.spath)
+        finally:
+            c.num_iterations = total
 
     def spath_resolve(self) -> np.ndarray:
         self.L.spath_raytracer_resolve(self.spath)

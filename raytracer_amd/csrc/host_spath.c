@@ -4,11 +4,12 @@
  *
  * The reference synchronises the host after each of its three launches per
  * iteration.  Nothing outside this library can see the per-pixel buffers
- * between two resolves, so render calls are only recorded (iteration counter,
- * the call's random value) and launched in batches: one rt_k_spath_run launch
- * covers every pending iteration, ending at the latest at the next resolve
- * point, where the frame is resolved and read back exactly when the reference
- * would have done it.
+ * between two resolves, so iterations are launched many at a time: one
+ * rt_k_spath_run launch covers up to max_batch iterations, and (run_ahead) it
+ * is issued by the first render call that needs one of them, for the calls
+ * after it as well.  The frame is resolved and read back exactly when the
+ * reference would have done it (every resolve_interval-th call), from the
+ * copy of the accumulator the kernel kept at that iteration.
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -73,10 +74,11 @@ spath_raytracer_context *init_spath_raytracer_context(struct _rt_ctx *rctx)
     c->resolve_interval = 50;        /* reference: src/spath_raytracer.c:389-390 */
     c->separate_kernels = 0;
     c->quiet = false;
-    c->max_batch = 64;
+    c->max_batch = 0;
+    c->run_ahead = 1;
     c->pending = 0;
-    c->pending_values = (unsigned int *)malloc(sizeof(unsigned int) * 1024);
-    c->cl_random_value_buffer = rt_mem_alloc(dev, sizeof(unsigned int) * 1024);
+    c->pending_values = (unsigned int *)malloc(sizeof(unsigned int) * RT_RUN_MAX_ITERS);
+    c->cl_random_value_buffer = rt_mem_alloc(dev, sizeof(unsigned int) * RT_RUN_MAX_ITERS);
     c->cl_pixel_cost_buffer = rt_mem_alloc(dev, ((size_t)n + 65536) * sizeof(unsigned int));   /* + room for a diagnostic build's per-wave time stamps */
     c->cl_pixel_order_buffer = rt_mem_alloc(dev, n * sizeof(unsigned int));
     c->cl_cost_hist_buffer = rt_mem_alloc(dev, 256 * sizeof(unsigned int));
@@ -109,95 +111,173 @@ static void upload_random_buffer(spath_raytracer_context *c)
     rt_mem_upload(rctx->rcl->device, c->cl_random_buffer, c->random_buffer, n * sizeof(unsigned int));
 }
 
-/* The parts of a schedule trial: the default schedule first and last, the alternatives between. */
+/* The timed launches of a calibration: the default schedule first and last, the alternatives between. */
 static const int trial_schedule[RT_TRIAL_PARTS] = { RT_SCHEDULE_ONE_LEAF_SLOT, RT_SCHEDULE_TWO_LEAF_SLOTS,
                                                     RT_SCHEDULE_SHORT_CHAINS, RT_SCHEDULE_ONE_LEAF_SLOT };
 static const char *schedule_name[RT_SCHEDULE_COUNT] = { "one leaf slot", "two leaf slots", "short chains" };
 
-/* Reads the timings of a queued schedule trial (waits for the launches) and keeps the fastest schedule.  An
-   alternative has to beat the better of the two default runs by 5 % to displace the default, so a slow first
-   launch (cold caches, clocks still ramping) cannot decide it. */
-static void finish_schedule_trial(spath_raytracer_context *c)
+#define RT_ORDER_MIN_PIXELS 65536u     /* smaller frames are served in index order with the default schedule */
+
+static unsigned int launch_cap(const spath_raytracer_context *c)
 {
-    if (c->trial_state != 1) return;
-    rt_device *dev = c->rctx->rcl->device;
-    float t[RT_TRIAL_PARTS];
-    for (int k = 0; k < RT_TRIAL_PARTS; k++)
-        t[k] = rt_event_elapsed_ms(dev, c->trial_marks[k], c->trial_marks[k + 1]) / (float)c->trial_iters[k];
-    float best = t[0] < t[RT_TRIAL_PARTS - 1] ? t[0] : t[RT_TRIAL_PARTS - 1];
-    best *= 0.95f;
-    c->schedule = RT_SCHEDULE_ONE_LEAF_SLOT;
-    for (int k = 1; k < RT_TRIAL_PARTS - 1; k++)
-        if (t[k] < best) { best = t[k]; c->schedule = trial_schedule[k]; }
-    for (int k = 0; k <= RT_TRIAL_PARTS; k++) { rt_event_release(dev, c->trial_marks[k]); c->trial_marks[k] = NULL; }
-    c->trial_state = 2;
-    if (!c->quiet)
-        printf("schedule trial: %.3f / %.3f / %.3f / %.3f ms per iteration -> %s\n", t[0], t[1], t[2], t[3],
-               schedule_name[c->schedule]);
+    unsigned int cap = c->max_batch ? c->max_batch : (c->resolve_interval ? 4u * c->resolve_interval : 64u);
+    if (c->resolve_interval && cap > RT_RUN_MAX_SNAPSHOTS * c->resolve_interval) cap = RT_RUN_MAX_SNAPSHOTS * c->resolve_interval;
+    if (cap > RT_RUN_MAX_ITERS) cap = RT_RUN_MAX_ITERS;
+    return cap ? cap : 1u;
 }
 
-/* Launches the iterations recorded since the last flush as one batch. */
-void spath_raytracer_flush(spath_raytracer_context *c)
+/* The order in which the next launch serves the pixels, from the walk costs the last one (of cost_iters iterations)
+   recorded: heaviest first.  Bucket width ~ 1/16 of a typical pixel's cost (about 32 steps per iteration): finer
+   buckets order better but scatter the pixels of a screen tile over more chunks, and the rays of a chunk then
+   diverge more.  cost_iters == 0: nothing is known yet, all pixels in one bucket, i.e. plain screen-tile order. */
+static void update_pixel_order(spath_raytracer_context *c, unsigned int cost_iters)
 {
-    finish_schedule_trial(c);        /* also with nothing pending: a caller that wants the decision flushes */
-    if (!c->pending) return;
     raytracer_context *rctx = c->rctx;
     rt_device *dev = rctx->rcl->device;
     const unsigned int n = rctx->width * rctx->height;
+    unsigned int shift = 0;
+    if (cost_iters == 0) rt_mem_zero(dev, c->cl_pixel_cost_buffer, sizeof(unsigned int) * (size_t)n);
+    else while ((32u * cost_iters) >> shift > 16u) shift++;
+    rt_k_pixel_order(dev, c->cl_pixel_cost_buffer, c->cl_pixel_order_buffer, c->cl_cost_hist_buffer, n, shift,
+                     rctx->width, c->cl_tile_scratch_buffer);
+    c->order_valid = true;
+}
+
+/* One rt_k_spath_run launch over iterations launched_upto+1 .. launched_upto+count; their random values are drawn
+   here, in iteration order. */
+static void launch_iterations(spath_raytracer_context *c, unsigned int count)
+{
+    raytracer_context *rctx = c->rctx;
+    rt_device *dev = rctx->rcl->device;
+    const unsigned int n = rctx->width * rctx->height;
+    const bool reorder = !c->no_reorder && n >= RT_ORDER_MIN_PIXELS;
     rt_spath_buffers b;
     spath_raytracer_fill_buffers(c, &b);
-    /* blocking upload: also orders this batch behind the previous one, so the
+    for (unsigned int k = 0; k < count; k++) c->pending_values[k] = next_random_value(c);
+    /* blocking upload: also orders this launch behind the previous one, so the
        table is not overwritten while a launch still reads it */
-    rt_mem_upload(dev, c->cl_random_value_buffer, c->pending_values, sizeof(unsigned int) * c->pending);
-    if (!c->order_valid && !c->no_reorder && n >= 65536) {
-        /* nothing is known about costs yet: all pixels in one bucket, i.e. plain screen-tile order */
-        rt_mem_zero(dev, c->cl_pixel_cost_buffer, sizeof(unsigned int) * (size_t)n);
-        rt_k_pixel_order(dev, c->cl_pixel_cost_buffer, c->cl_pixel_order_buffer, c->cl_cost_hist_buffer, n, 0,
-                         rctx->width, c->cl_tile_scratch_buffer);
-        c->order_valid = true;
+    rt_mem_upload(dev, c->cl_random_value_buffer, c->pending_values, sizeof(unsigned int) * count);
+    if (reorder && !c->order_valid) update_pixel_order(c, 0);
+
+    /* resolve points inside this launch: iterations first, first + r, ... <= last */
+    const unsigned int r = c->resolve_interval, a = c->launched_upto + 1, last = c->launched_upto + count;
+    const unsigned int first = r ? ((a + r - 1) / r) * r : 0;
+    c->snap_count = (r && first <= last) ? (last - first) / r + 1 : 0;
+    c->snap_first_iteration = c->snap_count ? first : 0;
+    if (c->snap_count > c->snapshot_slots) {
+        if (c->cl_snapshot_buffer) rt_mem_free(dev, c->cl_snapshot_buffer);
+        c->cl_snapshot_buffer = rt_mem_alloc(dev, (size_t)c->snap_count * n * sizeof(vec4));
+        c->snapshot_slots = c->snap_count;
     }
-    finish_schedule_trial(c);
-    const rt_mem order = (c->order_valid && !c->no_reorder) ? c->cl_pixel_order_buffer : NULL;
-    unsigned int cost_iters = c->pending;      /* iterations the cost buffer will describe: those of the last launch */
-    if (!c->schedule_fixed && c->trial_state == 0 && c->pending >= 4 * RT_TRIAL_PARTS && n >= 65536) {
-        /* the parts of this batch run back to back in the same pixel order, one schedule each */
-        unsigned int done = 0;
-        c->trial_marks[0] = rt_event_record(dev);
-        for (int k = 0; k < RT_TRIAL_PARTS; k++) {
-            const unsigned int part = (c->pending - done) / (unsigned int)(RT_TRIAL_PARTS - k);
-            c->trial_iters[k] = part;
-            rt_k_spath_run(dev, &rctx->stat_scene->kdt->view, &b, n, part,
-                           (char *)c->cl_random_value_buffer + sizeof(unsigned int) * done,
-                           c->cl_pixel_cost_buffer, order, trial_schedule[k]);
-            c->trial_marks[k + 1] = rt_event_record(dev);
-            done += part;
-            cost_iters = part;
-        }
-        c->trial_state = 1;
-    } else {
-        rt_k_spath_run(dev, &rctx->stat_scene->kdt->view, &b, n, c->pending, c->cl_random_value_buffer,
-                       c->cl_pixel_cost_buffer, order, c->schedule);
-    }
-    if (!c->no_reorder && n >= 65536) {
-        /* the next batch serves the pixels that were heaviest in this one first; bucket width ~ 1/16 of a
-           typical pixel's cost (about 32 steps per iteration): finer buckets order better but scatter the
-           pixels of a screen tile over more chunks, and the rays of a chunk then diverge more */
-        unsigned int shift = 0;
-        while ((32u * cost_iters) >> shift > 16u) shift++;
-        rt_k_pixel_order(dev, c->cl_pixel_cost_buffer, c->cl_pixel_order_buffer, c->cl_cost_hist_buffer, n, shift,
-                         rctx->width, c->cl_tile_scratch_buffer);
-        c->order_valid = true;
+    rt_k_spath_run_snap(dev, &rctx->stat_scene->kdt->view, &b, n, count, c->cl_random_value_buffer,
+                        c->cl_pixel_cost_buffer, (reorder && c->order_valid) ? c->cl_pixel_order_buffer : NULL, c->schedule,
+                        c->snap_count ? c->cl_snapshot_buffer : NULL, c->snap_count ? first - a + 1 : 0, r);
+    if (reorder) update_pixel_order(c, count);
+    c->launched_upto = last;
+    c->launches++;
+}
+
+/* Launches the iterations the caller has asked for and that are not launched yet (with run_ahead: up to a full
+   launch from there on).  Never past num_iterations. */
+void spath_raytracer_flush(spath_raytracer_context *c)
+{
+    const unsigned int asked = c->current_iteration < c->num_iterations ? c->current_iteration : c->num_iterations;
+    while (!c->separate_kernels && c->launched_upto < asked) {
+        const unsigned int count = (c->run_ahead ? c->num_iterations : asked) - c->launched_upto;
+        const unsigned int cap = launch_cap(c);
+        launch_iterations(c, count < cap ? count : cap);
     }
     c->pending = 0;
 }
 
-void spath_raytracer_resolve(spath_raytracer_context *c)
+static void resolve_from(spath_raytracer_context *c, rt_mem accum)
 {
     raytracer_context *rctx = c->rctx;
     const unsigned int n = rctx->width * rctx->height;
-    spath_raytracer_flush(c);
-    rt_k_resolve_avg(rctx->rcl->device, rctx->cl_output_buffer, c->cl_path_output_buffer, n);
+    rt_k_resolve_avg(rctx->rcl->device, rctx->cl_output_buffer, accum, n);
     rt_mem_download(rctx->rcl->device, rctx->output_buffer, rctx->cl_output_buffer, (size_t)n * 4);
+}
+
+void spath_raytracer_resolve(spath_raytracer_context *c)
+{
+    spath_raytracer_flush(c);
+    resolve_from(c, c->cl_path_output_buffer);
+}
+
+/* The frame as it stands after iteration `iteration` (a resolve point the caller has just reached). */
+static void resolve_at(spath_raytracer_context *c, unsigned int iteration)
+{
+    const size_t n = (size_t)c->rctx->width * c->rctx->height;
+    spath_raytracer_flush(c);
+    if (c->snap_count && iteration >= c->snap_first_iteration &&
+        (iteration - c->snap_first_iteration) % c->resolve_interval == 0 &&
+        (iteration - c->snap_first_iteration) / c->resolve_interval < c->snap_count) {
+        const size_t slot = (iteration - c->snap_first_iteration) / c->resolve_interval;
+        resolve_from(c, (char *)c->cl_snapshot_buffer + slot * n * sizeof(vec4));
+    } else if (c->launched_upto <= iteration) {
+        resolve_from(c, c->cl_path_output_buffer);       /* one launch per kernel per iteration: nothing has run ahead */
+    } else {
+        fprintf(stderr, "ERROR: no copy of the accumulator after iteration %u was kept (resolve_interval changed during a render?)\n", iteration);
+        exit(1);
+    }
+}
+
+void spath_raytracer_calibrate(spath_raytracer_context *c)
+{
+    raytracer_context *rctx = c->rctx;
+    rt_device *dev = rctx->rcl->device;
+    const unsigned int n = rctx->width * rctx->height;
+    if (c->separate_kernels || n < RT_ORDER_MIN_PIXELS) return;
+    unsigned int iters = c->calibration_iterations ? c->calibration_iterations : 12u;
+    if (iters > RT_RUN_MAX_ITERS) iters = RT_RUN_MAX_ITERS;
+
+    /* copies of everything a launch writes */
+    rt_spath_buffers b;
+    spath_raytracer_fill_buffers(c, &b);
+    rt_mem live[7] = { b.ray_o, b.ray_d, b.hits, b.prog_a, b.prog_b, b.random, b.out_tex };
+    const size_t bytes[7] = { 16, 16, 16, 16, 16, 4, 16 };
+    rt_mem saved[7];
+    for (int k = 0; k < 7; k++) {
+        saved[k] = rt_mem_alloc(dev, bytes[k] * n);
+        rt_mem_copy(dev, saved[k], live[k], bytes[k] * n);
+    }
+    /* random values of its own: the render's streams stay untouched */
+    for (unsigned int k = 0; k < iters; k++) c->pending_values[k] = splitmix32(0xca11b8u, k);
+    rt_mem_upload(dev, c->cl_random_value_buffer, c->pending_values, sizeof(unsigned int) * iters);
+
+    const bool reorder = !c->no_reorder;
+    const rt_mem order = reorder ? c->cl_pixel_order_buffer : NULL;
+    rt_event marks[RT_TRIAL_PARTS][2];
+    for (int k = -1; k < RT_TRIAL_PARTS; k++) {
+        /* launch -1 (default schedule, screen-tile order) only measures the pixels' costs: the timed launches and
+           the render's first launch serve the heaviest pixels first, as every later launch of the render will */
+        if (k == -1 && reorder) update_pixel_order(c, 0);
+        if (k >= 0) marks[k][0] = rt_event_record(dev);
+        rt_k_spath_run(dev, &rctx->stat_scene->kdt->view, &b, n, iters, c->cl_random_value_buffer, c->cl_pixel_cost_buffer,
+                       order, k < 0 ? RT_SCHEDULE_ONE_LEAF_SLOT : trial_schedule[k]);
+        if (k >= 0) marks[k][1] = rt_event_record(dev);
+        if (k == -1 && reorder) update_pixel_order(c, iters);
+        for (int j = 0; j < 7; j++) rt_mem_copy(dev, live[j], saved[j], bytes[j] * n);
+    }
+    for (int k = 0; k < RT_TRIAL_PARTS; k++) {
+        c->trial_ms[k] = rt_event_elapsed_ms(dev, marks[k][0], marks[k][1]) / (float)iters;
+        rt_event_release(dev, marks[k][0]);
+        rt_event_release(dev, marks[k][1]);
+    }
+    rt_device_sync(dev);
+    for (int k = 0; k < 7; k++) rt_mem_free(dev, saved[k]);
+
+    /* An alternative has to beat the better of the two default runs by 5 % to displace the default, so a slow
+       first launch (clocks still ramping) cannot decide it. */
+    const float *t = c->trial_ms;
+    float best = (t[0] < t[RT_TRIAL_PARTS - 1] ? t[0] : t[RT_TRIAL_PARTS - 1]) * 0.95f;
+    c->schedule = RT_SCHEDULE_ONE_LEAF_SLOT;
+    for (int k = 1; k < RT_TRIAL_PARTS - 1; k++)
+        if (t[k] < best) { best = t[k]; c->schedule = trial_schedule[k]; }
+    c->trial_state = 2;
+    if (!c->quiet)
+        printf("schedule calibration: %.3f / %.3f / %.3f / %.3f ms per iteration -> %s\n", t[0], t[1], t[2], t[3],
+               schedule_name[c->schedule]);
 }
 
 /* reference: src/spath_raytracer.c:404-436 */
@@ -208,14 +288,21 @@ void spath_raytracer_prepass(spath_raytracer_context *c)
     const unsigned int n = rctx->width * rctx->height;
     const size_t n16 = (size_t)n * sizeof(vec4);
 
-    finish_schedule_trial(c);        /* a decision taken for this scene is kept across renders */
     c->render_complete = false;
     c->num_iterations = 2048 * 4;
     c->rng_launch = 0;
     c->pending = 0;
+    c->launched_upto = 0;
+    c->launches = 0;
+    c->snap_count = 0;
+    c->snap_first_iteration = 0;
     c->order_valid = false;
     if (c->rng_mode == RT_RNG_LIBC) srand((unsigned int)rt_time_ms());
     c->start_time = rt_time_ms();
+    if (!c->quiet) {                 /* device times for the line printed at every resolve point */
+        rt_timing_enable(dev, 1);
+        rt_timing_reset(dev);
+    }
 
     rt_mem_zero(dev, c->cl_path_output_buffer, n16);
     raytracer_prepass(rctx);
@@ -243,6 +330,8 @@ void spath_raytracer_prepass(spath_raytracer_context *c)
        first iteration traces null rays and finishes one sky-only sample */
     rt_mem_zero(dev, rctx->cl_ray_buffer, n16);
     rt_mem_zero(dev, rctx->cl_ray_dir_buffer, n16);
+    /* a decision taken for this scene and frame is kept across renders */
+    if (!c->schedule_fixed && c->trial_state == 0) spath_raytracer_calibrate(c);
     rt_device_sync(dev);
 }
 
@@ -262,30 +351,51 @@ void spath_raytracer_render(spath_raytracer_context *c)
         spath_raytracer_flush(c);
         rt_k_xorshift(dev, b.random, n);
         if (!c->render_complete) {
-            spath_raytracer_resolve(c);
+            resolve_from(c, c->cl_path_output_buffer);
             if (!c->quiet) printf("Render took: %u ms\n", rt_time_ms() - c->start_time);
         }
         c->render_complete = true;
         return;
     }
 
-    const uint32_t rv = next_random_value(c);
     if (c->separate_kernels) {
+        const uint32_t rv = next_random_value(c);
         rt_k_xorshift(dev, b.random, n);
         rt_k_kd_intersect(dev, &kdt->view, b.ray_o, b.ray_d, b.hits, n);
         rt_k_spath_trace(dev, &kdt->view, &b, n, rv, 0);
-    } else {
-        unsigned int cap = c->max_batch ? c->max_batch : 64;
-        if (cap > 1024) cap = 1024;
-        c->pending_values[c->pending++] = rv;
-        if (c->pending >= cap || c->current_iteration == c->num_iterations) spath_raytracer_flush(c);
+        c->launched_upto = c->current_iteration;
+    } else if (c->current_iteration > c->launched_upto) {
+        /* running ahead: this call launches its iteration and the following ones; otherwise iterations are
+           collected until the launch is full, the render ends or the frame is due */
+        c->pending = c->current_iteration - c->launched_upto;
+        if (c->run_ahead || c->pending >= launch_cap(c) || c->current_iteration == c->num_iterations) spath_raytracer_flush(c);
     }
 
     if (c->resolve_interval && c->current_iteration % c->resolve_interval == 0) {
-        spath_raytracer_resolve(c);
-        if (!c->quiet)
-            printf("iteration %u  sample %u.%u/%u  elapsed %u ms\n", c->current_iteration, c->current_iteration / 4,
-                   c->current_iteration % 4, c->num_iterations / 4, rt_time_ms() - c->start_time);
+        const unsigned int t0 = rt_time_ms();
+        uint64_t launches = 0;
+        double run_ms = 0.0;
+        if (!c->quiet) {
+            /* device time of the render kernel since the last line; the reference prints host times of its three
+               launches here (src/spath_raytracer.c:396-399): traversal and shading are one kernel in this library */
+            rt_device_sync(dev);
+            rt_timing_get(dev, RT_K_SPATH_RUN, &launches, &run_ms);
+            if (c->separate_kernels) {
+                double ms2 = 0.0;
+                rt_timing_get(dev, RT_K_KD_INTERSECT, &launches, &run_ms);
+                rt_timing_get(dev, RT_K_SPATH_TRACE, &launches, &ms2);
+                run_ms += ms2;
+            }
+            rt_timing_reset(dev);
+        }
+        const unsigned int t1 = rt_time_ms();
+        resolve_at(c, c->current_iteration);
+        if (!c->quiet) {
+            const unsigned int t2 = rt_time_ms(), el = t2 - c->start_time;
+            printf("collision+trace: %.1f (device, %llu launches), wait: %u, draw: %u    %u.%u/%u    %u:%u:%u\n", run_ms,
+                   (unsigned long long)launches, t1 - t0, t2 - t1, c->current_iteration / 4, c->current_iteration % 4,
+                   c->num_iterations / 4, (el / 1000) / 60, (el / 1000) % 60, el % 1000);
+        }
     }
 }
 
@@ -293,7 +403,7 @@ void spath_raytracer_destroy(spath_raytracer_context *c)
 {
     if (!c) return;
     rt_device *dev = c->rctx->rcl->device;
-    finish_schedule_trial(c);
+    if (c->cl_snapshot_buffer) rt_mem_free(dev, c->cl_snapshot_buffer);
     rt_mem_free(dev, c->cl_path_output_buffer);
     rt_mem_free(dev, c->cl_path_ray_origin_buffer);
     rt_mem_free(dev, c->cl_path_ray_origin_dir_buffer);

@@ -659,11 +659,21 @@ struct SpathDev {
     uint32_t *random;
     uint32_t *cost;             // out: walk steps each pixel took in this launch
     const uint32_t *order;      // in: pixel to serve as j-th work item (nullptr = j)
+    float4 *snap;               // out: copies of out_tex at the launch's resolve points, [slot][pixel]
 };
+
+// A lane's progress through its pixel's iterations, in one register: iterations finished in this launch (bits
+// 10..0), snapshot slots filled (15..11), iterations left until the next snapshot (31..16).  Finishing an
+// iteration is one add.
+#define RT_IT_MASK 0x7ffu
+#define RT_IT_SLOT_SHIFT 11
+#define RT_IT_LEFT_SHIFT 16
+#define RT_IT_FINISHED_ONE 0xffff0001u   /* +1 finished, -1 left */
 
 template <int LDS_DEPTH, int SHADE_MIN, int CHUNK, int NI, int NT, int WAVES>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_spath_run(TravScene P, SpathDev B, uint32_t n, uint32_t iters,
-                                                  const uint32_t *__restrict__ rv, uint32_t *__restrict__ counter)
+                                                  const uint32_t *__restrict__ rv, uint32_t *__restrict__ counter,
+                                                  uint32_t snap_first, uint32_t snap_every)
 {
     __shared__ uint2 stack[LDS_DEPTH * 64];
     uint2 spill[RT_MAX_STACK - LDS_DEPTH];
@@ -699,12 +709,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                     o = mk3(0.f, 0.f, 0.f); d = mk3(0.f, 0.f, 0.f);
                 } else {
                     f3 no, nd;
-                    spath_step(B.tri_shade, h, o, d, rnd, rv[it], pix, B.out_tex, B.origin_o, B.origin_d,
+                    spath_step(B.tri_shade, h, o, d, rnd, rv[it & RT_IT_MASK], pix, B.out_tex, B.origin_o, B.origin_d,
                                B.source_hits, pa, pb, no, nd);
                     o = no; d = nd;
                 }
-                it++;
-                if (it == iters) {       // leave the buffers as the last per-iteration launches would
+                it += RT_IT_FINISHED_ONE;
+                if ((it >> RT_IT_LEFT_SHIFT) == 0u) {
+                    // the frame is resolved after this iteration: keep the pixel's accumulator as it stands now
+                    // (snap_first-th iteration of the launch, then every snap_every-th)
+                    B.snap[(size_t)((it >> RT_IT_SLOT_SHIFT) & 31u) * n + pix] = B.out_tex[pix];
+                    it += (snap_every << RT_IT_LEFT_SHIFT) + (1u << RT_IT_SLOT_SHIFT);
+                }
+                if ((it & RT_IT_MASK) == iters) {       // leave the buffers as the last per-iteration launches would
                     B.ray_o[pix] = mk4(o, 0.f);
                     B.ray_d[pix] = mk4(d, 0.f);
                     B.prog_a[pix] = pa;
@@ -727,7 +743,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                 pa = B.prog_a[pix];
                 pb = B.prog_b[pix];
                 rnd = B.random[pix];
-                it = 0;
+                it = snap_first << RT_IT_LEFT_SHIFT;
                 fresh = true;
             }
             // (c) start the walk of every new ray
@@ -1211,7 +1227,7 @@ void launch_kd_intersect(rt_device *dev, const TravScene &P, const float4 *ro, c
 
 template <int LDS_DEPTH, int SHADE_MIN, int CHUNK, int NI, int NT, int WAVES>
 void launch_run_variant(rt_device *dev, const TravScene &P, const SpathDev &B, uint32_t n, uint32_t iters,
-                        const uint32_t *rv)
+                        const uint32_t *rv, uint32_t snap_first, uint32_t snap_every)
 {
     auto kern = k_spath_run<LDS_DEPTH, SHADE_MIN, CHUNK, NI, NT, WAVES>;
     RT_HIP_CHECK(hipSetDevice(dev->ordinal));
@@ -1224,12 +1240,12 @@ void launch_run_variant(rt_device *dev, const TravScene &P, const SpathDev &B, u
     uint32_t *counter = dev->counters + 16 * dev->current;
     RT_HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(uint32_t), dev->stream));
     rt_launch_timer tm(dev, RT_K_SPATH_RUN);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, dev->stream, P, B, n, iters, rv, counter);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, dev->stream, P, B, n, iters, rv, counter, snap_first, snap_every);
     RT_HIP_CHECK(hipGetLastError());
 }
 
 void launch_spath_run(rt_device *dev, const TravScene &P, const SpathDev &B, uint32_t n, uint32_t iters, const uint32_t *rv,
-                      int schedule)
+                      int schedule, uint32_t snap_first, uint32_t snap_every)
 {
     // RT_RUN_VARIANT (environment, read once) overrides the schedule with one of the
     // compiled parameter sets, for tuning runs
@@ -1239,33 +1255,33 @@ void launch_spath_run(rt_device *dev, const TravScene &P, const SpathDev &B, uin
         variant = e ? atoi(e) : 0;
     }
     if (variant == 0 && schedule == RT_SCHEDULE_TWO_LEAF_SLOTS) {
-        launch_run_variant<12, 16, 64, 1, 2, 5>(dev, P, B, n, iters, rv);
+        launch_run_variant<12, 16, 64, 1, 2, 5>(dev, P, B, n, iters, rv, snap_first, snap_every);
         return;
     }
     if (variant == 0 && schedule == RT_SCHEDULE_SHORT_CHAINS) {
-        launch_run_variant<16, 16, 64, 2, 2, 5>(dev, P, B, n, iters, rv);
+        launch_run_variant<16, 16, 64, 2, 2, 5>(dev, P, B, n, iters, rv, snap_first, snap_every);
         return;
     }
     switch (variant) {
-    case 1: launch_run_variant<10, 16, 64, 2, 1, 7>(dev, P, B, n, iters, rv); break;
-    case 2: launch_run_variant<10, 8, 64, 1, 1, 7>(dev, P, B, n, iters, rv); break;
-    case 3: launch_run_variant<10, 24, 64, 1, 1, 7>(dev, P, B, n, iters, rv); break;
-    case 4: launch_run_variant<10, 32, 64, 1, 1, 7>(dev, P, B, n, iters, rv); break;
-    case 5: launch_run_variant<8, 16, 64, 1, 1, 7>(dev, P, B, n, iters, rv); break;
-    case 6: launch_run_variant<10, 12, 64, 1, 1, 7>(dev, P, B, n, iters, rv); break;
-    case 7: launch_run_variant<10, 20, 64, 1, 1, 7>(dev, P, B, n, iters, rv); break;
-    case 8: launch_run_variant<12, 16, 64, 1, 2, 6>(dev, P, B, n, iters, rv); break;
-    case 9: launch_run_variant<12, 16, 64, 1, 2, 5>(dev, P, B, n, iters, rv); break;   // = RT_SCHEDULE_TWO_LEAF_SLOTS
-    case 10: launch_run_variant<12, 16, 64, 2, 2, 5>(dev, P, B, n, iters, rv); break;
-    case 11: launch_run_variant<10, 16, 64, 1, 1, 8>(dev, P, B, n, iters, rv); break;
-    case 12: launch_run_variant<8, 16, 64, 1, 1, 8>(dev, P, B, n, iters, rv); break;
-    case 13: launch_run_variant<10, 16, 64, 1, 1, 6>(dev, P, B, n, iters, rv); break;
-    case 14: launch_run_variant<10, 16, 64, 1, 2, 7>(dev, P, B, n, iters, rv); break;
-    case 15: launch_run_variant<10, 16, 64, 2, 2, 7>(dev, P, B, n, iters, rv); break;
-    case 16: launch_run_variant<11, 16, 64, 1, 1, 7>(dev, P, B, n, iters, rv); break;
-    case 17: launch_run_variant<16, 16, 64, 2, 2, 5>(dev, P, B, n, iters, rv); break;   // = RT_SCHEDULE_SHORT_CHAINS
-    case 19: launch_run_variant<16, 16, 64, 1, 1, 5>(dev, P, B, n, iters, rv); break;
-    default: launch_run_variant<10, 16, 64, 1, 1, 7>(dev, P, B, n, iters, rv); break;
+    case 1: launch_run_variant<10, 16, 64, 2, 1, 7>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
+    case 2: launch_run_variant<10, 8, 64, 1, 1, 7>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
+    case 3: launch_run_variant<10, 24, 64, 1, 1, 7>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
+    case 4: launch_run_variant<10, 32, 64, 1, 1, 7>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
+    case 5: launch_run_variant<8, 16, 64, 1, 1, 7>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
+    case 6: launch_run_variant<10, 12, 64, 1, 1, 7>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
+    case 7: launch_run_variant<10, 20, 64, 1, 1, 7>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
+    case 8: launch_run_variant<12, 16, 64, 1, 2, 6>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
+    case 9: launch_run_variant<12, 16, 64, 1, 2, 5>(dev, P, B, n, iters, rv, snap_first, snap_every); break;   // = RT_SCHEDULE_TWO_LEAF_SLOTS
+    case 10: launch_run_variant<12, 16, 64, 2, 2, 5>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
+    case 11: launch_run_variant<10, 16, 64, 1, 1, 8>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
+    case 12: launch_run_variant<8, 16, 64, 1, 1, 8>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
+    case 13: launch_run_variant<10, 16, 64, 1, 1, 6>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
+    case 14: launch_run_variant<10, 16, 64, 1, 2, 7>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
+    case 15: launch_run_variant<10, 16, 64, 2, 2, 7>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
+    case 16: launch_run_variant<11, 16, 64, 1, 1, 7>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
+    case 17: launch_run_variant<16, 16, 64, 2, 2, 5>(dev, P, B, n, iters, rv, snap_first, snap_every); break;   // = RT_SCHEDULE_SHORT_CHAINS
+    case 19: launch_run_variant<16, 16, 64, 1, 1, 5>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
+    default: launch_run_variant<10, 16, 64, 1, 1, 7>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
     }
 }
 
@@ -1443,8 +1459,25 @@ void rt_k_pixel_order(rt_device *dev, rt_mem cost, rt_mem order, rt_mem hist256,
 void rt_k_spath_run(rt_device *dev, const rt_kd_view *kd, const rt_spath_buffers *b, uint32_t n, uint32_t iters,
                     rt_mem random_values, rt_mem cost, rt_mem order, int schedule)
 {
+    rt_k_spath_run_snap(dev, kd, b, n, iters, random_values, cost, order, schedule, NULL, 0, 0);
+}
+
+void rt_k_spath_run_snap(rt_device *dev, const rt_kd_view *kd, const rt_spath_buffers *b, uint32_t n, uint32_t iters,
+                         rt_mem random_values, rt_mem cost, rt_mem order, int schedule, rt_mem snapshots,
+                         uint32_t snap_first, uint32_t snap_every)
+{
     if (!n || !iters) return;
     check_kd(kd, "rt_k_spath_run");
+    if (iters > RT_RUN_MAX_ITERS) {
+        fprintf(stderr, "ERROR: rt_k_spath_run: %u iterations in one launch, the limit is %u\n", iters, RT_RUN_MAX_ITERS);
+        exit(1);
+    }
+    if (!snapshots || snap_first == 0 || snap_first > iters) {
+        snapshots = NULL; snap_first = 0xffffu; snap_every = 0;        // never reached
+    } else if (snap_every == 0 || (iters - snap_first) / snap_every + 1 > RT_RUN_MAX_SNAPSHOTS) {
+        fprintf(stderr, "ERROR: rt_k_spath_run: more than %u snapshots in one launch\n", RT_RUN_MAX_SNAPSHOTS);
+        exit(1);
+    }
     TravScene P;
     P.nodes = (const uint4 *)kd->nodes;
     P.leaf_tris = (const float4 *)kd->leaf_tris;
@@ -1459,8 +1492,9 @@ void rt_k_spath_run(rt_device *dev, const rt_kd_view *kd, const rt_spath_buffers
     B.prog_a = (float4 *)b->prog_a; B.prog_b = (float4 *)b->prog_b; B.random = (uint32_t *)b->random;
     B.cost = (uint32_t *)cost;
     B.order = (const uint32_t *)order;
+    B.snap = (float4 *)snapshots;
     if (!cost) { fprintf(stderr, "ERROR: rt_k_spath_run needs a per-pixel cost buffer\n"); exit(1); }
-    launch_spath_run(dev, P, B, n, iters, (const uint32_t *)random_values, schedule);
+    launch_spath_run(dev, P, B, n, iters, (const uint32_t *)random_values, schedule, snap_first, snap_every);
 }
 
 void rt_k_resolve_avg(rt_device *dev, rt_mem out_u32, rt_mem out_tex, uint32_t n)

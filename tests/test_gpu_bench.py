@@ -48,3 +48,36 @@ def test_two_ranks_render_the_same_frame():
                     launcher=launcher)
     assert two["n_gpus"] == 2
     assert two["config"]["frame_crc32"] == one["config"]["frame_crc32"]
+
+
+def test_plain_invocation_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it starts two ranks itself (here both on the one GPU,
+    over gloo) and prints the same frame checksum as one rank."""
+    args = ["--workload", "tiny", "--steps", "6", "--warmup", "2", "--no-cpu-baseline"]
+    one = run_bench(args)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update({"RT_BENCH_BACKEND": "gloo", "RT_BENCH_SHARE_GPU": "1"})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + args, cwd=ROOT, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, lines
+    two = json.loads(lines[0])
+    assert two["n_gpus"] == 2 and "ranks" in two["config"]["partition"]
+    assert two["config"]["frame_crc32"] == one["config"]["frame_crc32"]
+
+
+def test_more_gpus_than_visible_is_an_error():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "RT_BENCH_SHARE_GPU")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--workload", "tiny"], cwd=ROOT,
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert p.returncode != 0 and not p.stdout.strip()
+    assert b"GPU(s) are visible" in p.stderr
+
+
+def test_short_timed_region_is_one_launch():
+    """The command shape the round-end driver uses (--steps 20 --warmup 5): the timed region is ONE launch of 20
+    iterations; the schedule calibration happened in the prepass."""
+    d = run_bench(["--workload", "tiny", "--steps", "20", "--warmup", "5", "--no-cpu-baseline"])
+    assert d["roofline"]["launches"] == 1 and d["roofline"]["iterations_per_launch"] == 20
+    assert d["config"]["schedule_calibration_ms_per_iteration"] is not None

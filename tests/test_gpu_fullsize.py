@@ -118,7 +118,7 @@ def test_soup_scene_strip_against_oracle(rt, orc):
 
 def test_config2_full_frame_both_launch_structures(rt):
     """82 k-triangle scene at 1024x1024 (the ~70 k-triangle configuration): 64 iterations batched (with the
-    schedule trial and pixel reordering on their defaults) against one launch per kernel per iteration."""
+    schedule calibration, pixel reordering and run-ahead launches on their defaults) against one launch per kernel per iteration."""
     sc = rt.scenes.icosphere_scene(6)
     w = h = 1024
     a = rt.Renderer(sc, w, h).build()
@@ -135,10 +135,21 @@ def test_config2_full_frame_both_launch_structures(rt):
                         ("out_tex", 4)):
         assert_bits_equal(a.download(getattr(ba, name), np.uint32, words * n),
                           b.download(getattr(bb, name), np.uint32, words * n), name)
-    # the frame the caller saw at the last resolve point (iteration 50) is the same too
+    # the frame the caller saw at the last resolve point (iteration 50) is the same too: `a` ran all 64 iterations
+    # in one launch and resolved the copy of the accumulator it kept at iteration 50
     assert_bits_equal(a.output, b.output, "frame at the resolve point")
-    assert a.spath.contents.trial_state == 2
-    a.close(); b.close()
+    assert a.spath.contents.trial_state == 2 and a.spath.contents.launches == 1
+    assert min(a.spath.contents.trial_ms) > 0
+    # launches that hold only what has been asked for end at the resolve point: 50 + 14
+    c = rt.Renderer(sc, w, h).build()
+    c.init_spath(seed=5, resolve_interval=50, quiet=True, run_ahead=False)
+    c.spath_prepass(num_iterations=1 << 30)
+    c.spath_render(64)
+    assert c.spath.contents.launches == 2
+    assert_bits_equal(c.output, b.output, "frame at the resolve point, launches not running ahead")
+    bc = c.spath_buffers()
+    assert_bits_equal(c.download(bc.out_tex, np.uint32, 4 * n), b.download(bb.out_tex, np.uint32, 4 * n), "out_tex")
+    a.close(); b.close(); c.close()
 
 
 def test_config5_size_strip_against_oracle(rt, orc):
