@@ -69,6 +69,7 @@ typedef struct kd_tree_flat {
     uint32_t  num_nodes;    /* records */
     uint32_t  num_leaf_slots;
     uint32_t  root_ref;
+    uint32_t  max_depth;    /* interior nodes on the longest root-to-leaf path */
 } kd_tree_flat;
 
 /* reference: include/kdtree.h:65-91 */

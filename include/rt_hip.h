@@ -108,6 +108,7 @@ void     rt_event_release(rt_device *dev, rt_event e);
  * Replaces the serialised blob + index/vertex/normal image buffers that
  * kdtree_intersection and the shading kernels gather from
  * (src/kernels/kdtree.cl:49-65,263-277; src/kernels/path.cl:160-171). */
+#define RT_MAX_STACK 64   /* entries of a ray's traversal stack; a tree must be shallower than this */
 typedef struct rt_kd_view {
     rt_mem nodes;
     rt_mem leaf_tris;
@@ -118,6 +119,8 @@ typedef struct rt_kd_view {
     uint32_t root_ref;           /* reference of the root (a leaf descriptor for a one-leaf tree) */
     float scene_min[3];      /* SCENE_MIN / SCENE_MAX of src/raytracer.c:53-64 */
     float scene_max[3];
+    uint32_t max_depth;      /* interior nodes on the longest root-to-leaf path: bounds the traversal stack; the
+                                launches refuse a view with max_depth >= RT_MAX_STACK */
 } rt_kd_view;
 
 /* Original (un-flattened) scene arrays for the brute-force integrators

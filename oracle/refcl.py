@@ -62,9 +62,23 @@ def _lib():
     return _LIB
 
 
+class LauncherError(RuntimeError):
+    """A call of the HSA launcher failed; `what` names the call, `rc` is its return code (hr_dispatch: -9 means
+    the kernel was still running when the wait gave up -- its buffers must not be released any more)."""
+
+    def __init__(self, what, rc, message):
+        super().__init__(f"{what}: {message} (rc {rc})")
+        self.what, self.rc = what, rc
+
+    @property
+    def setup(self):
+        """True when the launcher could not be set up at all (no HSA agent, code object rejected): nothing ran."""
+        return self.what in ("hr_init", "hr_load")
+
+
 def _ok(rc, what):
     if rc != 0:
-        raise RuntimeError(f"{what}: {_lib().hr_last_error().decode()} (rc {rc})")
+        raise LauncherError(what, rc, _lib().hr_last_error().decode())
 
 
 class DevBuf:

@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 mkdir -p "$OUT"
 run() {
     name=$1; shift
-    timeout -s KILL 180 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -o "$name" -- \
+    timeout -s KILL 300 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -o "$name" -- \
         python3 bench.py --workload "$WL" --steps ${STEPS:-6} --warmup ${WARMUP:-2} --no-cpu-baseline ${BENCH_ARGS:-} > "$OUT/$name.log" 2>&1 || return 1
 }
 run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD || exit 1

@@ -520,7 +520,8 @@ void kd_tree_flatten(kd_tree *tree)
     f->root_ref = flatten_rec(&fc, tree->root, 0);
     f->num_nodes = fc.next_node;
     f->nodes = (uint32_t *)realloc(f->nodes, sizeof(uint32_t) * 8 * (size_t)(f->num_nodes ? f->num_nodes : 1));
-    if (fc.depth_max >= 64) {        /* the traversal stack holds 64 entries */
+    f->max_depth = fc.depth_max;
+    if (fc.depth_max >= RT_MAX_STACK) {        /* a ray pushes at most one entry per level */
         fprintf(stderr, "ERROR: kd-tree depth %u exceeds the traversal stack\n", fc.depth_max);
         exit(1);
     }

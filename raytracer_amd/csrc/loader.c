@@ -99,7 +99,27 @@ static int word_length(const char *t)
 
 /* Decimal text -> double the way the vendored parser does it
    (libs/tinyobj_loader_c.h:266-392): no rounding-correct conversion, every
-   digit is added in turn.  Returns 0 when the text is not a number (the caller
+   digit is added in turn.  The sequence of floating-point operations decides
+   the bits of every vertex, so this function follows tryParseDouble of
+   tinyobj_loader_c operation for operation; that code is
+
+     Copyright (c) 2016 Syoyo Fujita and many contributors, The MIT License (MIT).
+     Permission is hereby granted, free of charge, to any person obtaining a copy
+     of this software and associated documentation files (the "Software"), to deal
+     in the Software without restriction, including without limitation the rights
+     to use, copy, modify, merge, publish, distribute, sublicense, and/or sell
+     copies of the Software, and to permit persons to whom the Software is
+     furnished to do so, subject to the following conditions:
+     The above copyright notice and this permission notice shall be included in
+     all copies or substantial portions of the Software.
+     THE SOFTWARE IS PROVIDED "AS IS", WITHOUT WARRANTY OF ANY KIND, EXPRESS OR
+     IMPLIED, INCLUDING BUT NOT LIMITED TO THE WARRANTIES OF MERCHANTABILITY,
+     FITNESS FOR A PARTICULAR PURPOSE AND NONINFRINGEMENT. IN NO EVENT SHALL THE
+     AUTHORS OR COPYRIGHT HOLDERS BE LIABLE FOR ANY CLAIM, DAMAGES OR OTHER
+     LIABILITY, WHETHER IN AN ACTION OF CONTRACT, TORT OR OTHERWISE, ARISING FROM,
+     OUT OF OR IN CONNECTION WITH THE SOFTWARE OR THE USE OR OTHER DEALINGS IN
+     THE SOFTWARE.
+  Returns 0 when the text is not a number (the caller
    then uses 0.0).
    Defined here, undefined in the reference: a negative exponent or one above 30
    (the reference shifts 1 by the exponent); the value is mantissa * 10^exponent

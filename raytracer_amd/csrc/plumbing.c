@@ -63,8 +63,10 @@ void create_context(rcl_ctx *ctx)
         exit(1);
     }
     int ordinal = env_int("RT_DEVICE_ORDINAL", env_int("LOCAL_RANK", 0));
-    if (ordinal < 0) ordinal = 0;
-    ordinal %= n;
+    if (ordinal < 0 || ordinal >= n) {
+        fprintf(stderr, "Error: device %d asked for (RT_DEVICE_ORDINAL / LOCAL_RANK) but %d HIP device(s) are visible.\n", ordinal, n);
+        exit(1);
+    }
     memset(ctx, 0, sizeof *ctx);
     ctx->device_ordinal = ordinal;
     ctx->device = rt_device_open(ordinal);

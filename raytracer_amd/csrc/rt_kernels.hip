@@ -159,7 +159,6 @@ struct Hit { uint32_t tri; float t, u, v; };
 // [level][lane] so that a wave's accesses never collide on a bank whatever the
 // lanes' depths are; deeper entries (rare) spill to a per-lane private array.
 // ---------------------------------------------------------------------------
-#define RT_MAX_STACK 64
 #define RT_REF_LEAF 0x80000000u
 #define RT_REF_SLOT_MASK 0x03ffffffu
 #define RT_REF_COUNT(ref) (((ref) >> 26) & 31u)
@@ -1166,6 +1165,10 @@ void check_kd(const rt_kd_view *kd, const char *who)
         fprintf(stderr, "ERROR: %s: the flattened kd-tree has not been uploaded (no mesh triangles in the scene?)\n", who);
         exit(1);
     }
+    if (kd->max_depth >= RT_MAX_STACK) {
+        fprintf(stderr, "ERROR: %s: kd-tree depth %u does not fit the %d-entry traversal stack\n", who, kd->max_depth, RT_MAX_STACK);
+        exit(1);
+    }
 }
 
 // Resident one-wave blocks per CU of a persistent kernel on this device (asked of the runtime once per device
@@ -1365,7 +1368,8 @@ int rt_k_kd_intersect_noalloc(rt_device *dev, const rt_kd_view *kd, rt_mem ray_o
                         "(the 32-bit work counter is claimed in chunks past the end)\n", n, (unsigned)RT_NOALLOC_MAX_RAYS);
         return 1;
     }
-    if (!kd || !kd->nodes || !kd->leaf_tris || kd->num_leaf_slots == 0 || !ray_o || !ray_d || !hits || !dev->static_counters) {
+    if (!kd || !kd->nodes || !kd->leaf_tris || kd->num_leaf_slots == 0 || kd->max_depth >= RT_MAX_STACK || !ray_o ||
+        !ray_d || !hits || !dev->static_counters) {
         fprintf(stderr, "ERROR: rt_k_kd_intersect_noalloc: no flattened kd-tree, or a null ray / hit buffer\n");
         return 2;
     }

@@ -122,10 +122,17 @@ void scene_resource_push(raytracer_context *rctx)
         kdt->view.num_leaf_slots = kdt->flat.num_leaf_slots;
         kdt->view.num_tris = num_tris;
         kdt->view.root_ref = kdt->flat.root_ref;
+        kdt->view.max_depth = kdt->flat.max_depth;
         for (int k = 0; k < 3; k++) {
             kdt->view.scene_min[k] = through_percent_f(kdt->bounds.min[k]);
             kdt->view.scene_max[k] = through_percent_f(kdt->bounds.max[k]);
         }
+    }
+    if (!first_push && kdt->root && num_tris != kdt->view.num_tris) {
+        /* the flattened tree, its triangle slots and the shading table describe the triangles of the build */
+        fprintf(stderr, "ERROR: the scene has %u triangles now, the kd-tree was built for %u: geometry cannot change "
+                        "after raytracer_build\n", num_tris, kdt->view.num_tris);
+        exit(1);
     }
     if (kdt->root && (first_push || s->materials_changed || s->meshes_changed)) {
         float *table = build_tri_shade(s, num_tris);

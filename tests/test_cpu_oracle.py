@@ -299,3 +299,56 @@ def test_brute_force_integrators_against_outputs_of_the_reference_kernels(rt, or
             want = z["mixed2_path_trace_first"]
             assert (np.abs(fresh - want).max(axis=1) < 1e-4).mean() >= 0.99
             assert float(np.sqrt(np.mean((fresh - want) ** 2))) < 1e-2
+
+
+def test_reference_kernel_prelude_is_what_the_reference_host_would_print():
+    """oracle/build_ref_kernels.py hands the macro prelude to the compiler as -D options.  Here the prelude is
+    rebuilt from the TEXT of the reference's host code (the MACRO_GEN lines, the two sprintf formats, the os_macro
+    of the non-Windows branch and the order of the macros[] array, src/raytracer.c:38-70; MACRO_GEN itself,
+    include/parallel.h:7-10, stringizes its format, which collapses runs of blanks) with the scene's values, and
+    must be character for character the `#define NAME VALUE` lines the -D options stand for.  Needs the reference
+    checkout (read as text); skipped where it is not mounted."""
+    import os
+    import re
+    import sys
+    src = "/root/reference/src/raytracer.c"
+    if not os.path.exists(src):
+        pytest.skip("reference checkout not mounted")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "oracle"))
+    import build_ref_kernels as brk
+    import raytracer_amd.scenes as S
+
+    text = open(src).read()
+    body = text[text.index("void raytracer_build_kernels"):text.index("load_program_raw(rctx->rcl")]
+    gen = open("/root/reference/include/parallel.h").read()
+    assert re.search(r'sprintf\(n, "#define " #t, v\)', gen)               # the stringized format follows "#define "
+    formats = {}                                                             # variable -> (format, [value expressions])
+    for var, fmt, val in re.findall(r"MACRO_GEN\((\w+),\s*(.+?),\s*([^,]+?),\s*num_macros\);", body):
+        formats[var] = ("#define " + " ".join(fmt.split()), [val.strip()])
+    for var, fmt, args in re.findall(r'sprintf\((\w+), "([^"]+)",\s*((?:[^;]+?))\);', body):
+        formats[var] = (fmt, [a.strip() for a in args.split(",")])
+    other = re.search(r'#else\s*char os_macro\[\] = "([^"]+)";', body)
+    formats["os_macro"] = (other.group(1), [])
+    order = [v.strip() for v in re.search(r"char\* macros\[\]\s*=\s*\{([^}]+)\}", body).group(1).split(",")]
+    assert len(order) == 10 and set(order) == set(formats)
+
+    for sc in (S.icosphere_scene(4), S.mixed_scene(2), S.sphere_plane_scene()):
+        used = sc.verts4[np.unique(sc.idx4[:, 0]), :3] if sc.idx4.shape[0] else np.zeros((1, 3), np.float32)
+        lo, hi = used.min(axis=0), used.max(axis=0)
+        values = {"rctx->stat_scene->num_spheres": int(sc.spheres.shape[0]),
+                  "rctx->stat_scene->num_planes": int(sc.planes.shape[0]),
+                  "rctx->stat_scene->num_mesh_indices": int(sc.idx4.shape[0]),
+                  "rctx->stat_scene->num_meshes": int(sc.meshes.shape[0]),
+                  "rctx->stat_scene->num_materials": int(sc.materials.shape[0]),
+                  "rctx->rcl->simt_size": brk.SIMT_WIDTH, "rctx->rcl->num_simt_per_multiprocessor": 1}
+        for k in range(3):
+            values[f"rctx->stat_scene->kdt->bounds.min[{k}]"] = float(lo[k])    # float -> double, as C's varargs
+            values[f"rctx->stat_scene->kdt->bounds.max[{k}]"] = float(hi[k])
+        reference_prelude = "\n".join(formats[v][0] % tuple(values[a] for a in formats[v][1]) for v in order)
+        macros = brk.scene_macros(sc)
+        ours = {f"#define {k} {v}" for k, v in macros.items()}
+        assert ours == set(reference_prelude.split("\n")), (sorted(ours), reference_prelude)
+        # and in the reference's own order, as one text
+        by_name = {line.split()[1]: line for line in ours}
+        assert "\n".join(by_name[line.split()[1]] for line in reference_prelude.split("\n")) == reference_prelude
