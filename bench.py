@@ -43,6 +43,9 @@ WORKLOADS = {
     # name: (scene factory args, width, height, description)
     "c3": (("icosphere", 8), 2048, 2048, "1.31M-triangle displaced icosphere + room, 2048x2048, 4 bounces"),
     "c2": (("icosphere", 6), 1024, 1024, "81,920-triangle displaced icosphere + room, 1024x1024, 4 bounces"),
+    "c2obj": (("npz", "tests/golden/c2obj_scene.npz"), 1024, 1024,
+              "the reference's res/scenes/path_obj3.rsc with mesh/test3.obj (46,966 triangles) in place of the missing "
+              "happy.obj, 1024x1024, 4 bounces"),
     "c5": (("soup", 10_000_000), 3840, 2160, "10M-triangle random soup, 3840x2160"),
     "tiny": (("icosphere", 4), 256, 256, "5,120-triangle icosphere + room, 256x256 (smoke)"),
 }
@@ -57,6 +60,8 @@ def make_scene(spec):
     kind, arg = spec
     if kind == "icosphere":
         return scenes.icosphere_scene(arg)
+    if kind == "npz":
+        return scenes.scene_from_npz(os.path.join(ROOT, arg))
     return scenes.soup_scene(arg)
 
 
@@ -370,7 +375,8 @@ def main():
             "metric": "Mrays/sec (primary+bounce)", "value": round(value, 2), "unit": "Mrays/s",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32",
+            "data": "reference mesh files (frozen in tests/golden/c2obj_scene.npz), synthetic RNG streams" if spec[0] == "npz" else "synthetic",
             "config": {"workload": f"{args.workload}: {desc}", "triangles": int(sc.num_tris), "width": width,
                        "height": height, "rows_per_gpu": strip, "kernel": kname,
                        "schedule": int(r.spath.contents.schedule),

@@ -232,6 +232,17 @@ def mixed_scene(level: int = 2) -> SceneArrays:
     return _assemble([(pos, nrm, f, f, 4)], _materials(_PATH_MATERIALS), base.spheres, base.planes)
 
 
+def scene_from_npz(path: str) -> SceneArrays:
+    """Scene arrays stored by the fixture scripts under tests/golden (np.savez of a loaded scene)."""
+    z = np.load(path)
+
+    def rec(name, dt):
+        return z[name].view(dt).reshape(-1) if name in z.files and z[name].size else np.zeros(0, dt)
+    return SceneArrays(verts4=z["verts4"], normals4=z["normals4"], idx4=z["idx4"], meshes=rec("meshes", MESH_DT),
+                       materials=rec("materials", MATERIAL_DT), spheres=rec("spheres", SPHERE_DT),
+                       planes=rec("planes", PLANE_DT))
+
+
 def splitmix32(seed: int, index: np.ndarray) -> np.ndarray:
     """Counter-based 32-bit generator used to inject the per-pixel random
     buffer and the per-iteration random value deterministically (the reference

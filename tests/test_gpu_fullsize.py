@@ -173,3 +173,64 @@ def test_config5_size_strip_against_oracle(rt, orc):
         assert_bits_equal(g["out_tex"], st.out_tex, "out_tex")
         r.close()
     assert (st.source_results["t"] != 0).mean() > 0.3
+
+
+def _strip_against_oracle(rt, orc, sc, w, h, y0, rows, iters, seed):
+    r = rt.Renderer(sc, w, rows, tile_y0=y0, full_height=h).build()
+    r.init_spath(seed=seed, resolve_interval=0, quiet=True)
+    r.spath_prepass(num_iterations=iters)
+    r.spath_render(iters)
+    tree = _oracle_tree(orc, r, sc)
+    st = oracle_spath_run(orc, sc, tree, w, rows, seed, iters, y0=y0, full_h=h)
+    g = r.spath_state()
+    hits_equal(g["source_results"], st.source_results, "primary hits")
+    hits_equal(g["results"], st.results, "bounce hits")
+    assert_bits_equal(g["rays"], st.rays, "rays")
+    assert_bits_equal(g["progress"], st.progress, "progress")
+    assert_bits_equal(g["random"], st.random, "random")
+    assert_bits_equal(g["out_tex"], st.out_tex, "out_tex")
+    assert_bits_equal(r.spath_resolve(), st.resolve(), "resolved ARGB strip")
+    r.close()
+    return st
+
+
+def test_config2_on_the_reference_geometry(rt, orc):
+    """Configuration 2 on the reference's own files: res/scenes/path_obj3.rsc with mesh/test3.obj (its largest mesh,
+    46,966 triangles) where the scene names the missing happy.obj, light.obj and indigo_happy_walls.obj as the scene
+    arranges them (tests/golden/c2obj_scene.npz, written by make_c2obj_fixture.py from the reference's files through
+    the library's loader).  1024x1024: eight rows through the mesh against the oracle, bit for bit, over 13
+    iterations (three finished samples); then the whole frame, 64 iterations in one launch against one launch per
+    kernel per iteration, including the frame handed over at iteration 50."""
+    import os
+    sc = rt.scenes.scene_from_npz(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c2obj_scene.npz"))
+    assert sc.num_tris == 46972
+    w = h = 1024
+    st = _strip_against_oracle(rt, orc, sc, w, h, y0=448, rows=8, iters=13, seed=6)
+    mesh_of_hit = sc.idx4.reshape(-1, 4)[st.source_results["tri"], 3][st.source_results["t"] != 0]
+    assert (mesh_of_hit == 0).sum() > 200            # the strip crosses test3.obj itself, not only the walls
+    a = rt.Renderer(sc, w, h).build()
+    a.init_spath(seed=6, resolve_interval=50, quiet=True)
+    a.spath_prepass(num_iterations=64)
+    a.spath_render(64)
+    b = rt.Renderer(sc, w, h).build()
+    b.init_spath(seed=6, separate_kernels=True, resolve_interval=50, quiet=True)
+    b.spath_prepass(num_iterations=64)
+    b.spath_render(64)
+    n = w * h
+    ba, bb = a.spath_buffers(), b.spath_buffers()
+    for name, words in (("ray_o", 4), ("ray_d", 4), ("hits", 4), ("prog_a", 4), ("prog_b", 4), ("random", 1),
+                        ("out_tex", 4)):
+        assert_bits_equal(a.download(getattr(ba, name), np.uint32, words * n),
+                          b.download(getattr(bb, name), np.uint32, words * n), name)
+    assert_bits_equal(a.output, b.output, "frame at the resolve point")
+    assert a.spath.contents.launches == 1
+    a.close(); b.close()
+
+
+def test_reference_scene_path_obj2_bounces_against_oracle(rt, orc):
+    """The reference's scene res/scenes/path_obj2.rsc (the fixture of its stored render) beyond primary visibility:
+    eight rows of the 1920x1080 frame through the objects, 9 iterations of bounces, every buffer bit for bit."""
+    from helpers import load_ref_render_fixture
+    sc, w, h, _, _ = load_ref_render_fixture(rt)
+    st = _strip_against_oracle(rt, orc, sc, w, h, y0=600, rows=8, iters=9, seed=4)
+    assert (st.source_results["t"] != 0).mean() > 0.5 and st.out_tex[:, 3].max() >= 2

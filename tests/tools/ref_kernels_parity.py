@@ -28,11 +28,8 @@ from oracle import refcl            # noqa: E402
 from raytracer_amd import scenes    # noqa: E402
 
 
-def main():
-    iters = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-    flavour = sys.argv[2] if len(sys.argv) > 2 else "default"
-    workload = sys.argv[3] if len(sys.argv) > 3 else "c2"
-    seed = 1
+def compare(iters=256, flavour="default", workload="c2", seed=1, progress=True):
+    """Runs both sides and returns the figures (a dict)."""
     if workload == "c3":
         w = h = 2048
         sc = scenes.icosphere_scene(8)
@@ -62,7 +59,7 @@ def main():
         t0 = time.perf_counter()
         g.iterate(int(rv[k + 1]))
         t_ref += time.perf_counter() - t0
-        if (k + 1) % 32 == 0:
+        if progress and (k + 1) % 32 == 0:
             print(f"reference kernels: iteration {k + 1}", flush=True)
     ref_tex = g.out_tex
     ref_img8 = g.resolve()
@@ -94,7 +91,14 @@ def main():
            "resolved_pixels_equal": float((lv == 0).mean()), "resolved_within_1_level": float((lv <= 1).mean()),
            "ref_kernels_Mrays_per_s": round(n * iters / t_ref / 1e6, 1),
            "library_Mrays_per_s": round(n * iters / t_lib / 1e6, 1)}
-    print(json.dumps(out))
+    return out
+
+
+def main():
+    iters = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+    flavour = sys.argv[2] if len(sys.argv) > 2 else "default"
+    workload = sys.argv[3] if len(sys.argv) > 3 else "c2"
+    print(json.dumps(compare(iters, flavour, workload)))
 
 
 if __name__ == "__main__":
