@@ -211,11 +211,14 @@ void rt_k_xorshift(rt_device *dev, rt_mem random, uint32_t n);
    handed to lanes -- scheduling only, results do not depend on it.  schedule
    picks how many triangle slots follow the descend slot in each trip of the
    kernel's loop (RT_SCHEDULE_*): also scheduling only. */
-#define RT_SCHEDULE_ONE_LEAF_SLOT  0   /* scenes whose rays test about as many triangles as they fetch node records */
-#define RT_SCHEDULE_TWO_LEAF_SLOTS 1   /* triangle-heavy walks (unstructured soups, long leaves) */
-#define RT_SCHEDULE_SHORT_CHAINS   2   /* two descend and two leaf slots per trip, 16 stack levels in LDS: when the frame
-                                          (or a rank's share of it) has too few pixels to keep every lane busy, a batch
-                                          lasts as long as its heaviest pixel's chain of steps, and this shortens it */
+#define RT_SCHEDULE_ONE_LEAF_SLOT  0   /* one descend slot and one leaf slot per trip, 10 stack levels in LDS, 7 waves per SIMD */
+#define RT_SCHEDULE_TWO_AND_TWO    1   /* two descend and two leaf slots per trip (a slot no lane needs is jumped over), same
+                                          stack and occupancy: fewer trips per ray where rays run through long chains of
+                                          small steps; the best form on most mesh scenes, by a few per cent */
+#define RT_SCHEDULE_SHORT_CHAINS   2   /* two and two slots, 16 stack levels in LDS, 5 waves per SIMD: deep trees whose rays
+                                          would otherwise spill their stacks to memory (unstructured soups), and frames
+                                          (or a rank's share of one) with too few pixels to keep every lane busy, where a
+                                          batch lasts as long as its heaviest pixel's chain of steps */
 #define RT_SCHEDULE_COUNT          3
 #define RT_RUN_MAX_ITERS     1024u  /* iterations per launch */
 #define RT_RUN_MAX_SNAPSHOTS 32u

@@ -112,9 +112,9 @@ static void upload_random_buffer(spath_raytracer_context *c)
 }
 
 /* The timed launches of a calibration: the default schedule first and last, the alternatives between. */
-static const int trial_schedule[RT_TRIAL_PARTS] = { RT_SCHEDULE_ONE_LEAF_SLOT, RT_SCHEDULE_TWO_LEAF_SLOTS,
+static const int trial_schedule[RT_TRIAL_PARTS] = { RT_SCHEDULE_ONE_LEAF_SLOT, RT_SCHEDULE_TWO_AND_TWO,
                                                     RT_SCHEDULE_SHORT_CHAINS, RT_SCHEDULE_ONE_LEAF_SLOT };
-static const char *schedule_name[RT_SCHEDULE_COUNT] = { "one leaf slot", "two leaf slots", "short chains" };
+static const char *schedule_name[RT_SCHEDULE_COUNT] = { "one and one slot", "two and two slots", "short chains" };
 
 #define RT_ORDER_MIN_PIXELS 65536u     /* smaller frames are served in index order with the default schedule */
 

@@ -251,25 +251,14 @@ __device__ __forceinline__ void walk_descend(Walk &w, f3 o, f3 d, uint32_t k, fl
     w.li = en ? 0u : w.li;
 }
 
-// Lanes with `en` stand on an interior node: fetch its two-level record (32
-// bytes, layout in rt_hip.h) and descend -- from the record's top through one
-// of its children when that child is interior too, so up to two levels per
-// fetch; a lane that arrives at a child position (popped from the stack) takes
-// one.
+// The descend steps a two-level record (words a, r; layout in rt_hip.h) allows the lanes with `en`, which stand
+// on one of its nodes: from the record's top through one of its children when that child is interior too, so up
+// to two levels; a lane that stands on a child position (popped from the stack) takes one.
 template <int LDS_DEPTH>
-__device__ __forceinline__ void walk_interior(const TravScene &P, Walk &w, f3 o, f3 d, uint2 *__restrict__ col,
-                                              uint2 *__restrict__ spill, bool en)
+__device__ __forceinline__ void walk_record_steps(Walk &w, f3 o, f3 d, const uint4 &a, const uint4 &r,
+                                                  uint2 *__restrict__ col, uint2 *__restrict__ spill, bool en)
 {
     const uint32_t top = w.ref & ~3u;                    // reference of the record's top = record index * 4
-    uint4 a, r;
-    undefined_words(a); undefined_words(r);
-    if (en) {
-        const uint4 *rec = (const uint4 *)((const char *)P.nodes + (top << 3));
-        a = rec[0]; r = rec[1];
-    }
-    // both halves are fetched here, together: left alone, the compiler sinks the
-    // words only the first step needs into that step, as a second round trip
-    asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(r.x), "+v"(r.y), "+v"(r.z), "+v"(r.w));
     const uint32_t packed = a.w;
     const bool en1 = en & ((w.ref & 3u) == 0u);
     const uint32_t left = (packed & 64u) ? r.x : (top | 1u);
@@ -282,14 +271,60 @@ __device__ __forceinline__ void walk_interior(const TravScene &P, Walk &w, f3 o,
                             at_left ? r.x : r.z, at_left ? r.y : r.w, col, spill, en2);
 }
 
+// Lanes with `en` stand on an interior node: fetch its two-level record (32
+// bytes) and descend.
+template <int LDS_DEPTH>
+__device__ __forceinline__ void walk_interior(const TravScene &P, Walk &w, f3 o, f3 d, uint2 *__restrict__ col,
+                                              uint2 *__restrict__ spill, bool en)
+{
+    uint4 a, r;
+    undefined_words(a); undefined_words(r);
+    if (en) {
+        const uint4 *rec = (const uint4 *)((const char *)P.nodes + ((w.ref & ~3u) << 3));
+        a = rec[0]; r = rec[1];
+    }
+    // both halves are fetched here, together: left alone, the compiler sinks the
+    // words only the first step needs into that step, as a second round trip
+    asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(r.x), "+v"(r.y), "+v"(r.z), "+v"(r.w));
+    walk_record_steps<LDS_DEPTH>(w, o, d, a, r, col, spill, en);
+}
+
+// What leaving a leaf delivers (src/kernels/kdtree.cl:205-226): entry sp-1 of the stack -- the far child kept
+// back and the distance from which it counts -- together with the t_max that goes with it, which is the t_split
+// of entry sp-2 (scene_t_max at the bottom); with an empty stack, a restart at the root from t_max onwards.
+struct PopData { uint2 e; uint32_t below; };
+
+template <int LDS_DEPTH>
+__device__ __forceinline__ PopData walk_peek(const TravScene &P, const Walk &w, const uint2 *__restrict__ col,
+                                             const uint2 *__restrict__ spill, bool read)
+{
+    PopData p;
+    p.e = make_uint2(P.root_ref, __float_as_uint(w.t_max));
+    p.below = __float_as_uint(w.scene_t_max);
+    if (read) {
+        const uint32_t s = w.sp - 1u;
+        if (s < (uint32_t)LDS_DEPTH) {
+            p.e = col[s * 64];
+            const uint32_t under = col[(s > 0u ? s - 1u : 0u) * 64].y;
+            p.below = s > 0u ? under : p.below;
+        } else {
+            p.e = spill[s - LDS_DEPTH];
+            p.below = (s - 1u < (uint32_t)LDS_DEPTH) ? col[(LDS_DEPTH - 1) * 64].y : spill[s - 1u - LDS_DEPTH].y;
+        }
+    }
+    return p;
+}
+
 // One step of the lanes standing in a leaf (`in_leaf`), src/kernels/kdtree.cl:263-302:
 // test the next triangle, and when the leaf is used up pop / restart / end.
-// `has` says which of them have a triangle left, T0..T2 hold it.  true when the
-// lane's walk has ended (w.t_hit etc. hold the result, +inf for a miss).
+// `has` says which of them have a triangle left, T0..T2 hold it; `pd` is what
+// walk_peek read for the lanes that may leave the leaf (at least those with
+// sp != 0 whose leaf this step uses up).  true when the lane's walk has ended
+// (w.t_hit etc. hold the result, +inf for a miss); `moved` = the lane has left
+// the leaf for the node pd names.
 template <int LDS_DEPTH>
-__device__ __forceinline__ bool walk_leaf(const TravScene &P, Walk &w, f3 o, f3 d, const float4 &T0, const float4 &T1,
-                                          const float4 &T2, uint2 *__restrict__ col, uint2 *__restrict__ spill,
-                                          bool in_leaf, bool has)
+__device__ __forceinline__ bool walk_leaf_step(const TravScene &P, Walk &w, f3 o, f3 d, const float4 &T0, const float4 &T1,
+                                               const float4 &T2, const PopData &pd, bool in_leaf, bool has, bool &moved)
 {
     float t, u, v;
     const bool hit = tri_hit_edges(xyz(T0), xyz(T1), xyz(T2), o, d, t, u, v);
@@ -301,33 +336,36 @@ __device__ __forceinline__ bool walk_leaf(const TravScene &P, Walk &w, f3 o, f3 
     const bool finished = take & (t < w.t_max);
     w.li += has ? 1u : 0u;
 
-    // leaf used up: the reference's outer loop test, then restart or pop.  Entry
-    // sp-1 is popped; the t_max that goes with it is the t_split of entry sp-2
-    // (scene_t_max at the bottom).  A restart is a pop of {root, t_max} with
-    // scene_t_max below it.
+    // leaf used up: the reference's outer loop test, then restart or pop
     const bool used_up = in_leaf & !finished & (w.li >= w.lc);
     const bool ends = used_up & (((P.root_ref & RT_REF_LEAF) != 0u) | !(w.t_max < w.scene_t_max));
     const bool next = used_up & !ends;
     const bool pop = next & (w.sp != 0u);
-    uint2 e = make_uint2(P.root_ref, __float_as_uint(w.t_max));
-    uint32_t below = __float_as_uint(w.scene_t_max);
-    if (pop) {
-        const uint32_t s = w.sp - 1u;
-        if (s < (uint32_t)LDS_DEPTH) {
-            e = col[s * 64];
-            const uint32_t under = col[(s > 0u ? s - 1u : 0u) * 64].y;
-            below = s > 0u ? under : below;
-        } else {
-            e = spill[s - LDS_DEPTH];
-            below = (s - 1u < (uint32_t)LDS_DEPTH) ? col[(LDS_DEPTH - 1) * 64].y : spill[s - 1u - LDS_DEPTH].y;
-        }
-    }
     w.sp -= pop ? 1u : 0u;
-    w.t_min = next ? __uint_as_float(e.y) : w.t_min;
-    w.t_max = next ? __uint_as_float(below) : w.t_max;
-    w.ref = next ? e.x : w.ref;
+    w.t_min = next ? __uint_as_float(pd.e.y) : w.t_min;
+    w.t_max = next ? __uint_as_float(pd.below) : w.t_max;
+    w.ref = next ? pd.e.x : w.ref;
     w.li = next ? 0u : w.li;
+    moved = next;
     return finished | ends;
+}
+
+template <int LDS_DEPTH>
+__device__ __forceinline__ bool walk_leaf(const TravScene &P, Walk &w, f3 o, f3 d, const float4 &T0, const float4 &T1,
+                                          const float4 &T2, uint2 *__restrict__ col, uint2 *__restrict__ spill,
+                                          bool in_leaf, bool has)
+{
+    // the stack is read only by the lanes that pop: what they are is known once the triangle has been tested,
+    // so the test's decisions are taken twice here (the compiler folds them)
+    float t, u, v;
+    const bool hit = tri_hit_edges(xyz(T0), xyz(T1), xyz(T2), o, d, t, u, v);
+    const bool take = has & hit & !(t <= 0) & (t < w.t_hit);
+    const bool finished = take & (t < w.t_max);
+    const bool used_up = in_leaf & !finished & (w.li + (has ? 1u : 0u) >= w.lc);
+    const bool ends = used_up & (((P.root_ref & RT_REF_LEAF) != 0u) | !(w.t_max < w.scene_t_max));
+    const PopData pd = walk_peek<LDS_DEPTH>(P, w, col, spill, used_up & !ends & (w.sp != 0u));
+    bool moved;
+    return walk_leaf_step<LDS_DEPTH>(P, w, o, d, T0, T1, T2, pd, in_leaf, has, moved);
 }
 
 // walk_leaf with the triangle fetch: lanes that have a triangle left load it
@@ -353,6 +391,56 @@ __device__ __forceinline__ bool walk_leaf_load(const TravScene &P, Walk &w, f3 o
     const float4 T1 = make_float4(__uint_as_float(t1.x), __uint_as_float(t1.y), __uint_as_float(t1.z), __uint_as_float(t1.w));
     const float4 T2 = make_float4(__uint_as_float(t2.x), __uint_as_float(t2.y), __uint_as_float(t2.z), __uint_as_float(t2.w));
     return walk_leaf<LDS_DEPTH>(P, w, o, d, T0, T1, T2, col, spill, in_leaf, has);
+}
+
+// One trip of the walk with ONE memory round trip: the lanes standing on an interior node fetch its record, the
+// lanes standing in a leaf fetch their next triangle, and a lane about to use up its leaf (this is its last
+// triangle, or the leaf is empty) also fetches the record of the node it will continue at if the ray does not end
+// here -- the far child on top of its stack, or the root for a restart -- all in one batch of loads.  Then the
+// triangle is tested and the lanes whose leaf is used up pop; then every lane that holds the record of the node it
+// stands on descends (up to two levels).  A lane thus takes "descend", "triangle" or "triangle, pop, descend" per
+// round trip, where fetching records and triangles in two slots takes two dependent round trips per trip.  The
+// decisions are those of walk_descend / walk_leaf_step, so results do not depend on which form runs.
+template <int LDS_DEPTH>
+__device__ __forceinline__ bool walk_trip_fused(const TravScene &P, Walk &w, f3 o, f3 d, uint2 *__restrict__ col,
+                                                uint2 *__restrict__ spill, bool walking, uint32_t &steps)
+{
+    const bool in_leaf = walking & ((w.ref & RT_REF_LEAF) != 0u);
+    const bool in_node = walking & !(w.ref & RT_REF_LEAF);
+    steps += walking ? 1u : 0u;
+
+    const bool first = w.li == 0u;
+    const uint32_t count = RT_REF_COUNT(w.ref);
+    w.lc = first ? count : w.lc;
+    const bool has = in_leaf & (w.li < w.lc);
+    // a long leaf keeps its count with its first triangle: not known before that arrives, and never used up by it
+    const bool leaving = in_leaf & !(first & (count == 31u)) & (w.li + 1u >= w.lc);
+    const PopData pd = walk_peek<LDS_DEPTH>(P, w, col, spill, leaving & (w.sp != 0u));
+    const bool ahead = leaving & !(pd.e.x & RT_REF_LEAF);          // continues at an interior node: fetch it now
+
+    uint4 a, r, t0, t1, t2;
+    undefined_words(a); undefined_words(r); undefined_words(t0); undefined_words(t1); undefined_words(t2);
+    if (in_node | ahead) {
+        const uint32_t top = (in_node ? w.ref : pd.e.x) & ~3u;
+        const uint4 *rec = (const uint4 *)((const char *)P.nodes + (top << 3));
+        a = rec[0]; r = rec[1];
+    }
+    if (has) {
+        const uint4 *tp = (const uint4 *)((const char *)P.leaf_tris + ((w.ref & RT_REF_SLOT_MASK) + w.li) * 48u);
+        t0 = tp[0]; t1 = tp[1]; t2 = tp[2];
+    }
+    // all five loads leave here, together, before anything waits for one of them
+    asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(r.x), "+v"(r.y), "+v"(r.z), "+v"(r.w));
+    asm volatile("" : "+v"(t0.x), "+v"(t0.y), "+v"(t0.z), "+v"(t0.w), "+v"(t1.x), "+v"(t1.y), "+v"(t1.z), "+v"(t1.w),
+                      "+v"(t2.x), "+v"(t2.y), "+v"(t2.z));
+    w.lc = (first & (count == 31u)) ? t1.w : w.lc;
+    const float4 T0 = make_float4(__uint_as_float(t0.x), __uint_as_float(t0.y), __uint_as_float(t0.z), __uint_as_float(t0.w));
+    const float4 T1 = make_float4(__uint_as_float(t1.x), __uint_as_float(t1.y), __uint_as_float(t1.z), __uint_as_float(t1.w));
+    const float4 T2 = make_float4(__uint_as_float(t2.x), __uint_as_float(t2.y), __uint_as_float(t2.z), __uint_as_float(t2.w));
+    bool moved;
+    const bool fin = walk_leaf_step<LDS_DEPTH>(P, w, o, d, T0, T1, T2, pd, in_leaf, has, moved);
+    walk_record_steps<LDS_DEPTH>(w, o, d, a, r, col, spill, in_node | (moved & ahead));
+    return fin;
 }
 
 __device__ __forceinline__ Hit walk_result(const Walk &w)
@@ -393,7 +481,7 @@ __device__ __forceinline__ uint32_t queue_take(WorkQueue &q, bool want, uint32_t
 }
 
 // kdtree_intersection: every ray of ray_o/ray_d[0..n) -> hits[0..n).
-template <int LDS_DEPTH, int REFILL_MIN, int CHUNK>
+template <int LDS_DEPTH, int REFILL_MIN, int CHUNK, bool FUSED = false>
 __global__ __launch_bounds__(64) void k_kd_intersect(TravScene P, const float4 *__restrict__ ray_o,
                                                      const float4 *__restrict__ ray_d, Hit *__restrict__ hits,
                                                      uint32_t n, uint32_t *__restrict__ counter)
@@ -423,6 +511,14 @@ __global__ __launch_bounds__(64) void k_kd_intersect(TravScene P, const float4 *
         }
         if (!__any(walking)) {
             if (q.exhausted) break;
+            continue;
+        }
+        if (FUSED) {
+            uint32_t steps = 0;
+            if (walk_trip_fused<LDS_DEPTH>(P, w, o, d, col, spill, walking, steps)) {
+                hits[ridx] = walk_result(w);
+                walking = false;
+            }
             continue;
         }
         // one record (up to two descend steps) for the lanes on interior nodes,
@@ -754,6 +850,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
 #endif
         if (!__any(mode == WALK)) {
             if (q.exhausted && !__any(mode == DONE)) break;
+            continue;
+        }
+        if (NI == 0) {       // one round trip per trip: walk_trip_fused
+            const bool fin = walk_trip_fused<LDS_DEPTH>(P, w, o, d, col, spill, mode == WALK, steps);
+            mode = fin ? (uint32_t)DONE : mode;
             continue;
         }
         // up to NI records (two descend steps each), then up to NT triangles: a
@@ -1191,10 +1292,10 @@ int resident_blocks_per_cu(rt_device *dev, K kern)
 // as the chip keeps resident for this kernel (LDS-limited), never more than
 // there are 64-ray groups.  RT_TRAVERSE_VARIANT (environment, read once)
 // selects one of a few compiled parameter sets for tuning runs.
-template <int LDS_DEPTH, int REFILL_MIN, int CHUNK>
+template <int LDS_DEPTH, int REFILL_MIN, int CHUNK, bool FUSED = false>
 void launch_kd_variant(rt_device *dev, const TravScene &P, const float4 *ro, const float4 *rd, Hit *hits, uint32_t n)
 {
-    auto kern = k_kd_intersect<LDS_DEPTH, REFILL_MIN, CHUNK>;
+    auto kern = k_kd_intersect<LDS_DEPTH, REFILL_MIN, CHUNK, FUSED>;
     RT_HIP_CHECK(hipSetDevice(dev->ordinal));
     const int blocks_per_cu = resident_blocks_per_cu(dev, kern);
     static int waves_per_cu = -1;
@@ -1223,6 +1324,7 @@ void launch_kd_intersect(rt_device *dev, const TravScene &P, const float4 *ro, c
     switch (variant) {
     case 1: launch_kd_variant<16, 16, 256>(dev, P, ro, rd, hits, n); break;
     case 2: launch_kd_variant<8, 16, 256>(dev, P, ro, rd, hits, n); break;
+    case 3: launch_kd_variant<12, 16, 256, true>(dev, P, ro, rd, hits, n); break;
     default: launch_kd_variant<12, 16, 256>(dev, P, ro, rd, hits, n); break;
     }
 }
@@ -1257,8 +1359,8 @@ void launch_spath_run(rt_device *dev, const TravScene &P, const SpathDev &B, uin
         const char *e = getenv("RT_RUN_VARIANT");
         variant = e ? atoi(e) : 0;
     }
-    if (variant == 0 && schedule == RT_SCHEDULE_TWO_LEAF_SLOTS) {
-        launch_run_variant<12, 16, 64, 1, 2, 5>(dev, P, B, n, iters, rv, snap_first, snap_every);
+    if (variant == 0 && schedule == RT_SCHEDULE_TWO_AND_TWO) {
+        launch_run_variant<10, 16, 64, 2, 2, 7>(dev, P, B, n, iters, rv, snap_first, snap_every);
         return;
     }
     if (variant == 0 && schedule == RT_SCHEDULE_SHORT_CHAINS) {
@@ -1274,16 +1376,21 @@ void launch_spath_run(rt_device *dev, const TravScene &P, const SpathDev &B, uin
     case 6: launch_run_variant<10, 12, 64, 1, 1, 7>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
     case 7: launch_run_variant<10, 20, 64, 1, 1, 7>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
     case 8: launch_run_variant<12, 16, 64, 1, 2, 6>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
-    case 9: launch_run_variant<12, 16, 64, 1, 2, 5>(dev, P, B, n, iters, rv, snap_first, snap_every); break;   // = RT_SCHEDULE_TWO_LEAF_SLOTS
+    case 9: launch_run_variant<12, 16, 64, 1, 2, 5>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
     case 10: launch_run_variant<12, 16, 64, 2, 2, 5>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
     case 11: launch_run_variant<10, 16, 64, 1, 1, 8>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
     case 12: launch_run_variant<8, 16, 64, 1, 1, 8>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
     case 13: launch_run_variant<10, 16, 64, 1, 1, 6>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
     case 14: launch_run_variant<10, 16, 64, 1, 2, 7>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
-    case 15: launch_run_variant<10, 16, 64, 2, 2, 7>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
+    case 15: launch_run_variant<10, 16, 64, 2, 2, 7>(dev, P, B, n, iters, rv, snap_first, snap_every); break;   // = RT_SCHEDULE_TWO_AND_TWO
     case 16: launch_run_variant<11, 16, 64, 1, 1, 7>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
     case 17: launch_run_variant<16, 16, 64, 2, 2, 5>(dev, P, B, n, iters, rv, snap_first, snap_every); break;   // = RT_SCHEDULE_SHORT_CHAINS
     case 19: launch_run_variant<16, 16, 64, 1, 1, 5>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
+    case 20: launch_run_variant<10, 16, 64, 0, 0, 7>(dev, P, B, n, iters, rv, snap_first, snap_every); break;   // one round trip per trip
+    case 21: launch_run_variant<10, 16, 64, 0, 0, 6>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
+    case 22: launch_run_variant<12, 16, 64, 0, 0, 6>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
+    case 23: launch_run_variant<10, 16, 64, 0, 0, 8>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
+    case 24: launch_run_variant<16, 16, 64, 0, 0, 5>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
     default: launch_run_variant<10, 16, 64, 1, 1, 7>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
     }
 }
