@@ -1,4 +1,7 @@
-"""Time each rank's share of the c3 frame on one GPU, for contiguous strips or (argument: bands) interleaved bands."""
+"""Time each rank's share of the c3 frame on one GPU, for contiguous strips or (argument: bands) interleaved bands.
+STEPS (environment, default 100) iterations are timed after 50 of warm-up; they run as one launch."""
+import os
+STEPS = int(os.environ.get("STEPS", "100"))
 import sys, time
 sys.path.insert(0, '.')
 import raytracer_amd as rt
@@ -18,8 +21,8 @@ for N in ((8,) if len(sys.argv) > 2 else (2, 4, 8)):
         r.init_spath(seed=1, resolve_interval=50, quiet=True)
         r.spath_prepass(num_iterations=1 << 30)
         r.spath_render(50); r.sync()
-        t0 = time.perf_counter(); r.spath_render(100); r.sync(); ts.append(time.perf_counter() - t0)
+        t0 = time.perf_counter(); r.spath_render(STEPS); r.sync(); ts.append(time.perf_counter() - t0)
         picked.append(int(r.spath.contents.schedule))
         r.close()
-    full = 100 * W * H / 1e6
+    full = STEPS * W * H / 1e6
     print(N, [round(t * 1e3, 1) for t in ts], "max-based Mrays/s", round(full / max(ts)), "ideal(sum)", round(full / sum(ts) * N), "schedules", picked, flush=True)

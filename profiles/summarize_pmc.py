@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Average the rocprofv3 --pmc counters of one kernel over its dispatches.
-usage: profiles/summarize_pmc.py <dir with pass subdirs> <kernel substring> [skip_first_n]"""
+usage: profiles/summarize_pmc.py <dir with pass subdirs> <kernel substring> [skip_first_n | -last_n]
+A negative third argument keeps only the last n dispatches (the timed launches of a bench run come last: the
+calibration launches of the prepass and the warm-up precede them)."""
 import csv, glob, json, sys
 from collections import defaultdict
 
@@ -14,7 +16,7 @@ def main():
             if kern not in row["Kernel_Name"]:
                 continue
             per[int(row["Dispatch_Id"])][row["Counter_Name"]] += float(row["Counter_Value"])
-        ids = sorted(per)[skip:]
+        ids = sorted(per)[skip:]          # skip >= 0: drop the first ones; skip < 0: keep the last -skip
         if not ids:
             continue
         names = sorted({c for d in ids for c in per[d]})

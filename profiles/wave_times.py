@@ -1,6 +1,8 @@
-"""Diagnostic build only (make EXTRA_HIPFLAGS=-DRT_WAVE_TIMES): when do the waves of one 50-iteration launch start,
-see the work queue run dry, and exit?  Times in ms from the first wave's start (100 MHz wall clock)."""
+"""Diagnostic build only (rt_kernels.hip compiled with -DRT_WAVE_TIMES, library named by RT_LIB_PATH): when do
+the waves of one launch of ITERS iterations (argv[1], default 50) start, see the work queue run dry, and exit?
+Times in ms from the first wave's start (100 MHz wall clock)."""
 import sys
+ITERS = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 sys.path.insert(0, '.')
 import numpy as np
 import raytracer_amd as rt
@@ -10,10 +12,10 @@ r = rt.Renderer(sc, W, H).build()
 r.init_spath(seed=1, resolve_interval=50, quiet=True, schedule=0)
 r.spath_prepass(num_iterations=1 << 30)
 r.spath_render(100); r.sync()
-r.spath_render(50); r.sync()
+r.spath_render(ITERS); r.sync()
 n = W * H
 raw = r.download(r.spath.contents.cl_pixel_cost_buffer, np.uint32, n + 65536)[n:].reshape(-1, 4)
-raw = raw[:7168]
+raw = raw[(raw[:, 1] != 0)]
 t0 = raw[:, 0].min()
 start, end, dry, trips = [(raw[:, k] - t0).astype(np.int64) / 1e5 for k in (0, 1, 2)] + [raw[:, 3]]
 pct = [0, 1, 10, 50, 90, 99, 100]
