@@ -333,6 +333,7 @@ void spath_raytracer_prepass(spath_raytracer_context *c)
     /* a decision taken for this scene and frame is kept across renders */
     if (!c->schedule_fixed && c->trial_state == 0) spath_raytracer_calibrate(c);
     rt_device_sync(dev);
+    if (!c->quiet) rt_timing_reset(dev);      /* the lines printed at the resolve points count the render's launches only */
 }
 
 /* reference: src/spath_raytracer.c:355-402 */

@@ -156,6 +156,7 @@ void rt_timing_get(rt_device *dev, int kernel_id, uint64_t *launches, double *to
 rt_event rt_event_record(rt_device *dev)
 {
     hipEvent_t e;
+    RT_HIP_CHECK(hipSetDevice(dev->ordinal));      /* events belong to the device that is current when they are created */
     RT_HIP_CHECK(hipEventCreate(&e));
     RT_HIP_CHECK(hipEventRecord(e, dev->stream));
     return (rt_event)e;
@@ -208,6 +209,7 @@ static hipEvent_t take_event(rt_device *dev)
         return e;
     }
     hipEvent_t e;
+    RT_HIP_CHECK(hipSetDevice(dev->ordinal));
     RT_HIP_CHECK(hipEventCreate(&e));
     return e;
 }
