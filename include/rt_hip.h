@@ -58,6 +58,13 @@ void   rt_mem_free(rt_device *dev, rt_mem m);
 void   rt_mem_upload(rt_device *dev, rt_mem dst, const void *src, size_t bytes);   /* blocking write */
 void   rt_mem_download(rt_device *dev, void *dst, rt_mem src, size_t bytes);       /* blocking read, retrieve_buf */
 void   rt_mem_zero(rt_device *dev, rt_mem m, size_t bytes);                        /* zero_buffer (queued) */
+/* Page-locked host memory, and a host-to-device copy from it that is only queued on the current stream: the caller
+   must leave the source alone until the stream has passed the copy (rt_event_record + rt_event_elapsed_ms /
+   rt_device_sync).  For small tables a launch needs, so that launches queue back to back without a host round trip. */
+void  *rt_host_alloc(rt_device *dev, size_t bytes);
+void   rt_host_free(rt_device *dev, void *p);
+void   rt_mem_upload_queued(rt_device *dev, rt_mem dst, const void *pinned_src, size_t bytes);
+
 void   rt_mem_copy(rt_device *dev, rt_mem dst, rt_mem src, size_t bytes);          /* clEnqueueCopyBuffer (queued) */
 
 /* ---- timing with HIP events on the device's stream ---------------------- */
@@ -81,6 +88,7 @@ typedef void *rt_event;
 rt_event rt_event_record(rt_device *dev);
 float    rt_event_elapsed_ms(rt_device *dev, rt_event start, rt_event stop);
 void     rt_event_release(rt_device *dev, rt_event e);
+void     rt_event_wait(rt_device *dev, rt_event e);     /* the host waits until the stream has passed the marker */
 
 /* ---- scene data as the kernels see it ------------------------------------ */
 /* Flattened kd-tree (built by kd_tree_flatten, kdtree.h).

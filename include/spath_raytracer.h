@@ -53,8 +53,10 @@ typedef struct spath_raytracer_context {
     unsigned int max_batch;           /* most iterations folded into one launch; 0 = four resolve intervals (64 when
                                          resolve_interval is 0), at most RT_RUN_MAX_ITERS */
     unsigned int pending;             /* iterations accepted by spath_raytracer_render but not launched yet */
-    unsigned int *pending_values;     /* random values of the iterations of the launch being put together */
-    rt_mem       cl_random_value_buffer;
+    unsigned int *pending_values;     /* random values of the launches being put together: two tables of RT_RUN_MAX_ITERS
+                                         words in page-locked memory, used in turn, so that a launch can be queued while
+                                         the one before it still runs */
+    rt_mem       cl_random_value_buffer;   /* the same two tables on the device */
     rt_mem       cl_pixel_cost_buffer;   /* walk steps per pixel in the last batch */
     rt_mem       cl_pixel_order_buffer;  /* pixels by decreasing cost: service order of the next batch */
     rt_mem       cl_cost_hist_buffer;
@@ -84,6 +86,7 @@ typedef struct spath_raytracer_context {
     unsigned int snap_first_iteration;   /* iteration whose accumulator slot 0 holds (0: the last launch took none) */
     unsigned int snap_count;
     unsigned int launches;               /* rt_k_spath_run launches since the prepass (diagnostic) */
+    rt_event     values_uploaded[2];     /* marker behind the last upload from each of the two value tables */
 } spath_raytracer_context;
 
 spath_raytracer_context *init_spath_raytracer_context(struct _rt_ctx *rctx);   /* src/spath_raytracer.c:39-116 */

@@ -144,7 +144,7 @@ class spath_raytracer_context(C.Structure):
                 ("trial_ms", C.c_float * 4), ("calibration_iterations", C.c_uint),
                 ("run_ahead", C.c_int), ("launched_upto", C.c_uint), ("cl_snapshot_buffer", C.c_void_p),
                 ("snapshot_slots", C.c_uint), ("snap_first_iteration", C.c_uint), ("snap_count", C.c_uint),
-                ("launches", C.c_uint)]
+                ("launches", C.c_uint), ("values_uploaded", C.c_void_p * 2)]
 
 
 class rt_device_props(C.Structure):
@@ -175,7 +175,7 @@ EXPORTED_SYMBOLS = [
     # rt_hip.h
     "rt_device_count", "rt_device_open", "rt_device_close", "rt_device_get_props", "rt_device_sync",
     "rt_device_stream", "rt_device_ordinal", "rt_device_select_stream", "rt_mem_alloc", "rt_mem_free", "rt_mem_upload", "rt_mem_download",
-    "rt_mem_zero", "rt_mem_copy", "rt_event_record", "rt_event_elapsed_ms", "rt_event_release", "rt_timing_enable", "rt_timing_reset", "rt_timing_get", "rt_kernel_name",
+    "rt_mem_zero", "rt_mem_copy", "rt_host_alloc", "rt_host_free", "rt_mem_upload_queued", "rt_event_wait", "rt_event_record", "rt_event_elapsed_ms", "rt_event_release", "rt_timing_enable", "rt_timing_reset", "rt_timing_get", "rt_kernel_name",
     "rt_k_generate_rays", "rt_k_kd_intersect", "rt_k_kd_intersect_noalloc", "rt_k_spath_init", "rt_k_spath_trace", "rt_k_xorshift",
     "rt_k_spath_run", "rt_k_spath_run_snap", "rt_k_pixel_order", "rt_k_resolve_avg", "rt_k_cast_rays", "rt_k_path_trace", "rt_k_f_buffer_average",
     "rt_k_f_to_byte",

@@ -77,8 +77,8 @@ spath_raytracer_context *init_spath_raytracer_context(struct _rt_ctx *rctx)
     c->max_batch = 0;
     c->run_ahead = 1;
     c->pending = 0;
-    c->pending_values = (unsigned int *)malloc(sizeof(unsigned int) * RT_RUN_MAX_ITERS);
-    c->cl_random_value_buffer = rt_mem_alloc(dev, sizeof(unsigned int) * RT_RUN_MAX_ITERS);
+    c->pending_values = (unsigned int *)rt_host_alloc(dev, sizeof(unsigned int) * 2 * RT_RUN_MAX_ITERS);
+    c->cl_random_value_buffer = rt_mem_alloc(dev, sizeof(unsigned int) * 2 * RT_RUN_MAX_ITERS);
     c->cl_pixel_cost_buffer = rt_mem_alloc(dev, ((size_t)n + 65536) * sizeof(unsigned int));   /* + room for a diagnostic build's per-wave time stamps */
     c->cl_pixel_order_buffer = rt_mem_alloc(dev, n * sizeof(unsigned int));
     c->cl_cost_hist_buffer = rt_mem_alloc(dev, 256 * sizeof(unsigned int));
@@ -153,10 +153,18 @@ static void launch_iterations(spath_raytracer_context *c, unsigned int count)
     const bool reorder = !c->no_reorder && n >= RT_ORDER_MIN_PIXELS;
     rt_spath_buffers b;
     spath_raytracer_fill_buffers(c, &b);
-    for (unsigned int k = 0; k < count; k++) c->pending_values[k] = next_random_value(c);
-    /* blocking upload: also orders this launch behind the previous one, so the
-       table is not overwritten while a launch still reads it */
-    rt_mem_upload(dev, c->cl_random_value_buffer, c->pending_values, sizeof(unsigned int) * count);
+    /* the value tables are used in turn: this launch may be queued while the previous one still reads its table;
+       the one before that has long finished when its table comes round again, and the marker makes sure */
+    const unsigned int slot = c->launches & 1u;
+    unsigned int *values = c->pending_values + (size_t)slot * RT_RUN_MAX_ITERS;
+    const rt_mem d_values = (char *)c->cl_random_value_buffer + sizeof(unsigned int) * (size_t)slot * RT_RUN_MAX_ITERS;
+    if (c->values_uploaded[slot]) {
+        rt_event_wait(dev, c->values_uploaded[slot]);
+        rt_event_release(dev, c->values_uploaded[slot]);
+        c->values_uploaded[slot] = NULL;
+    }
+    for (unsigned int k = 0; k < count; k++) values[k] = next_random_value(c);
+    rt_mem_upload_queued(dev, d_values, values, sizeof(unsigned int) * count);
     if (reorder && !c->order_valid) update_pixel_order(c, 0);
 
     /* resolve points inside this launch: iterations first, first + r, ... <= last */
@@ -169,9 +177,10 @@ static void launch_iterations(spath_raytracer_context *c, unsigned int count)
         c->cl_snapshot_buffer = rt_mem_alloc(dev, (size_t)c->snap_count * n * sizeof(vec4));
         c->snapshot_slots = c->snap_count;
     }
-    rt_k_spath_run_snap(dev, &rctx->stat_scene->kdt->view, &b, n, count, c->cl_random_value_buffer,
+    rt_k_spath_run_snap(dev, &rctx->stat_scene->kdt->view, &b, n, count, d_values,
                         c->cl_pixel_cost_buffer, (reorder && c->order_valid) ? c->cl_pixel_order_buffer : NULL, c->schedule,
                         c->snap_count ? c->cl_snapshot_buffer : NULL, c->snap_count ? first - a + 1 : 0, r);
+    c->values_uploaded[slot] = rt_event_record(dev);      /* the launch has read the table once this marker is passed */
     if (reorder) update_pixel_order(c, count);
     c->launched_upto = last;
     c->launches++;
@@ -418,7 +427,9 @@ void spath_raytracer_destroy(spath_raytracer_context *c)
     rt_mem_free(dev, c->cl_pixel_order_buffer);
     rt_mem_free(dev, c->cl_cost_hist_buffer);
     if (c->cl_tile_scratch_buffer) rt_mem_free(dev, c->cl_tile_scratch_buffer);
-    free(c->pending_values);
+    for (int k = 0; k < 2; k++)
+        if (c->values_uploaded[k]) rt_event_release(dev, c->values_uploaded[k]);
+    rt_host_free(dev, c->pending_values);
     free(c->random_buffer);
     free(c);
 }

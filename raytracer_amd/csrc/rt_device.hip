@@ -120,6 +120,34 @@ void rt_mem_download(rt_device *dev, void *dst, rt_mem src, size_t bytes)
     RT_HIP_CHECK(hipStreamSynchronize(dev->stream));
 }
 
+void *rt_host_alloc(rt_device *dev, size_t bytes)
+{
+    void *p = nullptr;
+    RT_HIP_CHECK(hipSetDevice(dev->ordinal));
+    RT_HIP_CHECK(hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault));
+    return p;
+}
+
+void rt_host_free(rt_device *dev, void *p)
+{
+    if (!p) return;
+    RT_HIP_CHECK(hipSetDevice(dev->ordinal));
+    rt_device_sync(dev);
+    RT_HIP_CHECK(hipHostFree(p));
+}
+
+void rt_mem_upload_queued(rt_device *dev, rt_mem dst, const void *pinned_src, size_t bytes)
+{
+    if (!bytes) return;
+    RT_HIP_CHECK(hipMemcpyAsync(dst, pinned_src, bytes, hipMemcpyHostToDevice, dev->stream));
+}
+
+void rt_event_wait(rt_device *dev, rt_event e)
+{
+    (void)dev;
+    if (e) RT_HIP_CHECK(hipEventSynchronize((hipEvent_t)e));
+}
+
 void rt_mem_zero(rt_device *dev, rt_mem m, size_t bytes)
 {
     if (!bytes) return;
