@@ -70,7 +70,7 @@ void   rt_mem_copy(rt_device *dev, rt_mem dst, rt_mem src, size_t bytes);       
 /* ---- timing with HIP events on the device's stream ---------------------- */
 enum {
     RT_K_GENERATE_RAYS = 0, RT_K_KD_INTERSECT, RT_K_SPATH_INIT, RT_K_SPATH_TRACE, RT_K_XORSHIFT,
-    RT_K_RESOLVE_AVG, RT_K_CAST_RAYS, RT_K_PATH_TRACE, RT_K_F_AVERAGE, RT_K_F_TO_BYTE, RT_K_SPATH_RUN, RT_K_PIXEL_ORDER, RT_K_COUNT
+    RT_K_RESOLVE_AVG, RT_K_CAST_RAYS, RT_K_PATH_TRACE, RT_K_F_AVERAGE, RT_K_F_TO_BYTE, RT_K_SPATH_RUN, RT_K_PIXEL_ORDER, RT_K_DEBUG_DRAW, RT_K_COUNT
 };
 /* When enabled, every launch below is bracketed by two events; the totals are
    read back (after a sync) with rt_timing_get and cleared with rt_timing_reset. */
@@ -255,6 +255,12 @@ void rt_k_pixel_order(rt_device *dev, rt_mem cost, rt_mem order, rt_mem hist256,
 
 /* f_buffer_to_byte_buffer_avg (src/kernels/path.cl:428-444; host src/spath_raytracer.c:252-277). */
 void rt_k_resolve_avg(rt_device *dev, rt_mem out_u32, rt_mem out_tex, uint32_t n);
+
+/* kdtree_ray_draw (src/kernels/kdtree.cl:323-341; host src/spath_raytracer.c:173-199) and kdtree_test_draw
+   (src/kernels/kdtree.cl:344-384; host src/spath_raytracer.c:201-235): the reference's debug probes -- ray origins,
+   and the interpolated normals of a traversal's hits, as ARGB colours ((value + 1) / 2 per channel). */
+void rt_k_kd_ray_draw(rt_device *dev, rt_mem out_u32, rt_mem ray_o, uint32_t n);
+void rt_k_kd_test_draw(rt_device *dev, const rt_kd_view *kd, rt_mem out_u32, rt_mem hits, uint32_t n);
 
 /* cast_ray_test (src/kernels/ray.cl:17-105; host src/ss_raytracer.c:7-56). */
 void rt_k_cast_rays(rt_device *dev, const rt_scene_view *sc, rt_mem out_u32, rt_mem ray_o, rt_mem ray_d, uint32_t n);

@@ -92,6 +92,8 @@ typedef struct spath_raytracer_context {
 spath_raytracer_context *init_spath_raytracer_context(struct _rt_ctx *rctx);   /* src/spath_raytracer.c:39-116 */
 void spath_raytracer_render(spath_raytracer_context *ctx);                      /* src/spath_raytracer.c:355-402 */
 void spath_raytracer_prepass(spath_raytracer_context *ctx);                     /* src/spath_raytracer.c:404-436 */
+void spath_raytracer_ray_test(spath_raytracer_context *ctx);                    /* src/spath_raytracer.c:173-199 (debug view) */
+void spath_raytracer_kd_test(spath_raytracer_context *ctx);                     /* src/spath_raytracer.c:201-235 (debug view) */
 
 /* not in the reference */
 void spath_raytracer_flush(spath_raytracer_context *ctx);     /* launch whatever render calls are still pending */

@@ -350,3 +350,25 @@ def f_to_byte(tex: np.ndarray) -> np.ndarray:
     out = np.zeros(tex.shape[0], np.uint32)
     lib().orc_f_to_byte(_p(out), _p(tex), C.c_uint32(tex.shape[0]))
     return out
+
+
+def kd_ray_draw(rays: np.ndarray) -> np.ndarray:
+    """kdtree_ray_draw, src/kernels/kdtree.cl:323-341: (origin + 1) / 2 as a colour."""
+    rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
+    tex = np.ones((rays.shape[0], 4), np.float32)
+    tex[:, :3] = (rays[:, 0:3] + np.float32(1)) / np.float32(2)
+    return f_to_byte(tex)
+
+
+def kd_test_draw(scene, results: np.ndarray) -> np.ndarray:
+    """kdtree_test_draw, src/kernels/kdtree.cl:344-384: the normal interpolated at each hit, (n + 1) / 2 as a
+    colour; a miss (t == 0) is get_colour(0)."""
+    idx = scene.idx4.reshape(-1, 4)
+    tri = results["tri"].astype(np.int64)
+    u, v = results["u"][:, None], results["v"][:, None]
+    n1, n2, n3 = (scene.normals4[idx[tri + k, 1], :3] for k in range(3))
+    normal = (n1 * ((np.float32(1) - u) - v) + n2 * u) + n3 * v
+    tex = np.ones((len(tri), 4), np.float32)
+    tex[:, :3] = (normal + np.float32(1)) / np.float32(2)
+    tex[results["t"] == 0] = 0
+    return f_to_byte(tex)

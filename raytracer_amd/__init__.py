@@ -28,7 +28,7 @@ RT_RNG_LIBC, RT_RNG_SPLITMIX = 0, 1
 
 KERNEL_IDS = {"generate_rays": 0, "kd_intersect": 1, "spath_init": 2, "spath_trace": 3, "xorshift": 4,
               "resolve_avg": 5, "cast_rays": 6, "path_trace": 7, "f_buffer_average": 8, "f_to_byte": 9,
-              "spath_run": 10, "pixel_order": 11}
+              "spath_run": 10, "pixel_order": 11, "debug_draw": 12}
 
 HIT_DT = np.dtype([("tri", "<u4"), ("t", "<f4"), ("u", "<f4"), ("v", "<f4")])
 
@@ -177,7 +177,7 @@ EXPORTED_SYMBOLS = [
     "rt_device_stream", "rt_device_ordinal", "rt_device_select_stream", "rt_mem_alloc", "rt_mem_free", "rt_mem_upload", "rt_mem_download",
     "rt_mem_zero", "rt_mem_copy", "rt_host_alloc", "rt_host_free", "rt_mem_upload_queued", "rt_event_wait", "rt_event_record", "rt_event_elapsed_ms", "rt_event_release", "rt_timing_enable", "rt_timing_reset", "rt_timing_get", "rt_kernel_name",
     "rt_k_generate_rays", "rt_k_kd_intersect", "rt_k_kd_intersect_noalloc", "rt_k_spath_init", "rt_k_spath_trace", "rt_k_xorshift",
-    "rt_k_spath_run", "rt_k_spath_run_snap", "rt_k_pixel_order", "rt_k_resolve_avg", "rt_k_cast_rays", "rt_k_path_trace", "rt_k_f_buffer_average",
+    "rt_k_spath_run", "rt_k_spath_run_snap", "rt_k_pixel_order", "rt_k_resolve_avg", "rt_k_kd_ray_draw", "rt_k_kd_test_draw", "rt_k_cast_rays", "rt_k_path_trace", "rt_k_f_buffer_average",
     "rt_k_f_to_byte",
     # loader.h
     "load_scene_json", "load_scene_json_url", "load_file", "rt_set_resource_root", "rt_obj_parse", "rt_obj_free",
@@ -202,6 +202,7 @@ EXPORTED_SYMBOLS = [
     "init_ss_raytracer_context", "ss_raytracer_render", "ss_raytracer_prepass",
     "init_path_raytracer_context", "path_raytracer_render", "path_raytracer_prepass",
     "init_spath_raytracer_context", "spath_raytracer_render", "spath_raytracer_prepass",
+    "spath_raytracer_ray_test", "spath_raytracer_kd_test",
     "spath_raytracer_resolve", "spath_raytracer_flush", "spath_raytracer_fill_buffers", "spath_raytracer_calibrate",
     "ss_raytracer_destroy", "path_raytracer_destroy", "spath_raytracer_destroy",
 ]
@@ -274,6 +275,8 @@ def lib():
                                       vp, u32, u32]
     L.rt_k_pixel_order.argtypes = [vp, vp, vp, vp, u32, u32, u32, vp]
     L.rt_k_resolve_avg.argtypes = [vp, vp, vp, u32]
+    L.rt_k_kd_ray_draw.argtypes = [vp, vp, vp, u32]
+    L.rt_k_kd_test_draw.argtypes = [vp, C.POINTER(rt_kd_view), vp, vp, u32]
     L.rt_k_f_buffer_average.argtypes = [vp, vp, vp, u32, u32]
     L.rt_k_f_to_byte.argtypes = [vp, vp, vp, u32]
 
@@ -306,7 +309,7 @@ def lib():
     L.init_spath_raytracer_context.restype = C.POINTER(spath_raytracer_context)
     L.init_spath_raytracer_context.argtypes = [C.POINTER(raytracer_context)]
     for f in ("spath_raytracer_render", "spath_raytracer_prepass", "spath_raytracer_resolve", "spath_raytracer_flush",
-              "spath_raytracer_calibrate"):
+              "spath_raytracer_calibrate", "spath_raytracer_ray_test", "spath_raytracer_kd_test"):
         getattr(L, f).argtypes = [C.POINTER(spath_raytracer_context)]
     L.spath_raytracer_fill_buffers.argtypes = [C.POINTER(spath_raytracer_context), C.POINTER(rt_spath_buffers)]
     L.spath_raytracer_destroy.argtypes = [C.POINTER(spath_raytracer_context)]

@@ -289,6 +289,28 @@ void spath_raytracer_calibrate(spath_raytracer_context *c)
                schedule_name[c->schedule]);
 }
 
+/* The reference's two debug views (commented out of its render loop, src/spath_raytracer.c:400): the current rays'
+   origins, and the normals at the current rays' hits, drawn into output_buffer.
+   reference: src/spath_raytracer.c:173-199 and :201-235 */
+void spath_raytracer_ray_test(spath_raytracer_context *c)
+{
+    raytracer_context *rctx = c->rctx;
+    const unsigned int n = rctx->width * rctx->height;
+    spath_raytracer_flush(c);
+    rt_k_kd_ray_draw(rctx->rcl->device, rctx->cl_output_buffer, rctx->cl_ray_buffer, n);
+    rt_mem_download(rctx->rcl->device, rctx->output_buffer, rctx->cl_output_buffer, (size_t)n * 4);
+}
+
+void spath_raytracer_kd_test(spath_raytracer_context *c)
+{
+    raytracer_context *rctx = c->rctx;
+    const unsigned int n = rctx->width * rctx->height;
+    spath_raytracer_flush(c);
+    rt_k_kd_test_draw(rctx->rcl->device, &rctx->stat_scene->kdt->view, rctx->cl_output_buffer,
+                      c->cl_path_collision_result_buffer, n);
+    rt_mem_download(rctx->rcl->device, rctx->output_buffer, rctx->cl_output_buffer, (size_t)n * 4);
+}
+
 /* reference: src/spath_raytracer.c:404-436 */
 void spath_raytracer_prepass(spath_raytracer_context *c)
 {

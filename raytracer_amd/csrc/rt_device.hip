@@ -5,7 +5,7 @@
 
 static const char *k_kernel_names[RT_K_COUNT] = {
     "generate_rays", "kd_intersect", "spath_init", "spath_trace", "xorshift",
-    "resolve_avg", "cast_rays", "path_trace", "f_buffer_average", "f_to_byte", "spath_run", "pixel_order"};
+    "resolve_avg", "cast_rays", "path_trace", "f_buffer_average", "f_to_byte", "spath_run", "pixel_order", "debug_draw"};
 
 extern "C" {
 
@@ -107,6 +107,7 @@ void rt_mem_free(rt_device *dev, rt_mem m)
 void rt_mem_upload(rt_device *dev, rt_mem dst, const void *src, size_t bytes)
 {
     if (!bytes) return;
+    RT_HIP_CHECK(hipSetDevice(dev->ordinal));
     rt_device_sync(dev);       /* blocking transfer: ordered behind everything queued on any stream */
     RT_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, dev->stream));
     RT_HIP_CHECK(hipStreamSynchronize(dev->stream));
@@ -115,6 +116,7 @@ void rt_mem_upload(rt_device *dev, rt_mem dst, const void *src, size_t bytes)
 void rt_mem_download(rt_device *dev, void *dst, rt_mem src, size_t bytes)
 {
     if (!bytes) return;
+    RT_HIP_CHECK(hipSetDevice(dev->ordinal));
     rt_device_sync(dev);
     RT_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, dev->stream));
     RT_HIP_CHECK(hipStreamSynchronize(dev->stream));
@@ -139,6 +141,7 @@ void rt_host_free(rt_device *dev, void *p)
 void rt_mem_upload_queued(rt_device *dev, rt_mem dst, const void *pinned_src, size_t bytes)
 {
     if (!bytes) return;
+    RT_HIP_CHECK(hipSetDevice(dev->ordinal));
     RT_HIP_CHECK(hipMemcpyAsync(dst, pinned_src, bytes, hipMemcpyHostToDevice, dev->stream));
 }
 
@@ -151,12 +154,14 @@ void rt_event_wait(rt_device *dev, rt_event e)
 void rt_mem_zero(rt_device *dev, rt_mem m, size_t bytes)
 {
     if (!bytes) return;
+    RT_HIP_CHECK(hipSetDevice(dev->ordinal));
     RT_HIP_CHECK(hipMemsetAsync(m, 0, bytes, dev->stream));
 }
 
 void rt_mem_copy(rt_device *dev, rt_mem dst, rt_mem src, size_t bytes)
 {
     if (!bytes) return;
+    RT_HIP_CHECK(hipSetDevice(dev->ordinal));
     RT_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, dev->stream));
 }
 
@@ -244,6 +249,9 @@ static hipEvent_t take_event(rt_device *dev)
 
 rt_launch_timer::rt_launch_timer(rt_device *d, int kernel_id) : dev(d), id(kernel_id)
 {
+    // every launcher constructs one of these right before its launch: a process may hold rt_devices on several
+    // GPUs, and a launch (or an event) goes to the device that is current
+    RT_HIP_CHECK(hipSetDevice(dev->ordinal));
     if (!dev->timing) return;
     if (dev->slots[id].start.size() >= 16384) {   // bound the number of live events
         rt_device_sync(dev);

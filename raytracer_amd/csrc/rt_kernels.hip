@@ -1005,6 +1005,28 @@ __global__ void k_resolve_avg(uint32_t *__restrict__ out, const float4 *__restri
     out[i] = (d.w == 0) ? get_colour(0.f, 0.f, 0.f, 0.f) : get_colour(d.x / d.w, d.y / d.w, d.z / d.w, d.w / d.w);
 }
 
+// kdtree_ray_draw, reference: src/kernels/kdtree.cl:323-341 -- the rays' origins as colours (debug probe)
+__global__ void k_kd_ray_draw(uint32_t *__restrict__ out, const float4 *__restrict__ ray_o, uint32_t n)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 o = ray_o[i];
+    out[i] = get_colour((o.x + 1) / 2, (o.y + 1) / 2, (o.z + 1) / 2, 1.0f);
+}
+
+// kdtree_test_draw, reference: src/kernels/kdtree.cl:344-384 -- the interpolated normal at each hit as a colour,
+// black where the ray missed (debug probe of a traversal result)
+__global__ void k_kd_test_draw(uint32_t *__restrict__ out, const float4 *__restrict__ tri_shade,
+                               const Hit *__restrict__ hits, uint32_t n)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Hit h = hits[i];
+    if (h.t == 0) { out[i] = get_colour(0.f, 0.f, 0.f, 0.f); return; }
+    const f3 nrm = surface_at(tri_shade, h).normal;
+    out[i] = get_colour((nrm.x + 1) / 2, (nrm.y + 1) / 2, (nrm.z + 1) / 2, 1.0f);
+}
+
 // f_buffer_to_byte_buffer, reference: src/kernels/path.cl:447-458
 __global__ void k_f_to_byte(uint32_t *__restrict__ out, const float4 *__restrict__ tex, uint32_t n)
 {
@@ -1614,6 +1636,25 @@ void rt_k_resolve_avg(rt_device *dev, rt_mem out_u32, rt_mem out_tex, uint32_t n
     rt_launch_timer tm(dev, RT_K_RESOLVE_AVG);
     hipLaunchKernelGGL(k_resolve_avg, dim3(blocks_for(n, 256)), dim3(256), 0, dev->stream, (uint32_t *)out_u32,
                        (const float4 *)out_tex, n);
+    RT_AFTER_LAUNCH();
+}
+
+void rt_k_kd_ray_draw(rt_device *dev, rt_mem out_u32, rt_mem ray_o, uint32_t n)
+{
+    if (!n) return;
+    rt_launch_timer tm(dev, RT_K_DEBUG_DRAW);
+    hipLaunchKernelGGL(k_kd_ray_draw, dim3(blocks_for(n, 256)), dim3(256), 0, dev->stream, (uint32_t *)out_u32,
+                       (const float4 *)ray_o, n);
+    RT_AFTER_LAUNCH();
+}
+
+void rt_k_kd_test_draw(rt_device *dev, const rt_kd_view *kd, rt_mem out_u32, rt_mem hits, uint32_t n)
+{
+    if (!n) return;
+    check_kd(kd, "rt_k_kd_test_draw");
+    rt_launch_timer tm(dev, RT_K_DEBUG_DRAW);
+    hipLaunchKernelGGL(k_kd_test_draw, dim3(blocks_for(n, 256)), dim3(256), 0, dev->stream, (uint32_t *)out_u32,
+                       (const float4 *)kd->tri_shade, (const Hit *)hits, n);
     RT_AFTER_LAUNCH();
 }
 

@@ -63,3 +63,28 @@ def test_config1_full_size(rt, orc):
     got = r.download(r.path.contents.cl_path_fresh_frame_buffer, np.float32, 4 * w * h).reshape(-1, 4)
     assert (got.view(np.uint32) != fresh.view(np.uint32)).any(axis=1).mean() <= 0.005
     r.close()
+
+
+def test_debug_views_bit_exact(rt, orc):
+    """The reference's two debug probes (spath_raytracer_ray_test / _kd_test, src/spath_raytracer.c:173-235 over
+    kdtree_ray_draw / kdtree_test_draw, src/kernels/kdtree.cl:323-384) after a prepass and after five iterations:
+    ray origins and hit normals as colours, against the oracle."""
+    import numpy as np
+    from helpers import assert_bits_equal, oracle_spath_run
+    sc = rt.scenes.icosphere_scene(4)
+    tree = orc.KdTree(sc.verts4, sc.idx4)
+    w, h, seed = 96, 64, 12
+    r = rt.Renderer(sc, w, h).build()
+    r.init_spath(seed=seed, resolve_interval=0)
+    r.spath_prepass(num_iterations=5)
+    for iters in (0, 5):
+        if iters:
+            r.spath_render(iters)
+        st = oracle_spath_run(orc, sc, tree, w, h, seed, iters)
+        r.L.spath_raytracer_ray_test(r.spath)
+        assert_bits_equal(r.output, orc.kd_ray_draw(st.rays), f"ray origins after {iters} iterations")
+        r.L.spath_raytracer_kd_test(r.spath)
+        want = orc.kd_test_draw(sc, st.results if iters else st.source_results)
+        assert_bits_equal(r.output, want, f"hit normals after {iters} iterations")
+        assert len(np.unique(want)) > 50
+    r.close()

@@ -115,6 +115,28 @@ def test_integer_kernels_bit_exact(orc, refcl, rt):
     assert differ == 0, f"{differ} of {n} packed pixels differ"
 
 
+def test_debug_probe_kernels_bit_exact(orc, refcl, rt):
+    """kdtree_ray_draw and kdtree_test_draw (src/kernels/kdtree.cl:323-384) as compiled from the reference (strict
+    flavour) against the oracle's restatement, which the library's rt_k_kd_ray_draw / rt_k_kd_test_draw reproduce bit
+    for bit (tests/test_gpu_integrators.py): bounce rays of a 96x64 frame and their hits."""
+    sc, tree, rs = _scene(rt, orc, refcl, "ico4", "strict")
+    w, h = 96, 64
+    n = w * h
+    st = oracle_spath_run(orc, sc, tree, w, h, 12, 3)
+    rays = st.rays
+    hits = tree.intersect(rays)
+    assert tree.ray_stack(rays).max() <= 16
+    out = refcl.DevBuf.zeros(4 * n)
+    rs.prog.launch("kdtree_ray_draw", [out, refcl.DevBuf.of(rays), w], n)
+    assert_bits_equal(out.read(np.uint32, n), orc.kd_ray_draw(rays), "kdtree_ray_draw")
+    out = refcl.DevBuf.zeros(4 * n)
+    rs.prog.launch("kdtree_test_draw", [out, refcl.DevBuf.of(hits), rs.materials, rs.meshes, rs.indices, rs.vertices,
+                                         rs.normals, w], n)
+    got, want = out.read(np.uint32, n), orc.kd_test_draw(sc, hits)
+    assert_bits_equal(got, want, "kdtree_test_draw")
+    assert (hits["t"] != 0).sum() > 1000 and len(np.unique(want)) > 50
+
+
 def test_generate_rays_within_2_ulp(orc, refcl, rt):
     """generate_rays (src/kernels/ray.cl:109-133) goes through the built-in normalize (rsqrt based in ROCm's
     library, sqrt + divide in the oracle): directions agree to 2 ulp, origins exactly."""
