@@ -106,6 +106,18 @@ void spath_raytracer_resolve(spath_raytracer_context *ctx);   /* flush, then res
    before), draws nothing from the random streams, and leaves the pixel order of the first real launch behind:
    rendered results do not depend on it.  Frames under 65,536 pixels and separate_kernels mode keep the default. */
 void spath_raytracer_calibrate(spath_raytracer_context *ctx);
+
+/* Checkpoint / resume (the reference keeps its progressive state on the device only and has neither).
+   spath_raytracer_save launches what is pending, waits, and writes the render's state -- every per-pixel buffer,
+   the iteration the device has reached (launches may have run ahead of current_iteration: the checkpoint is taken
+   there) and the position in the random streams -- to `path`.  spath_raytracer_restore reads it into a context of
+   the same frame size and row mapping on the same scene that has been through spath_raytracer_prepass, and sets
+   current_iteration to the checkpoint's; rendering on from there gives, in RT_RNG_SPLITMIX mode, bit for bit what the
+   uninterrupted render gives (RT_RNG_LIBC draws from rand(), whose state is not the library's to save).  Both
+   return 0, or non-zero with a message on stderr and the context untouched when the file cannot be written / read or
+   does not fit the context. */
+int spath_raytracer_save(spath_raytracer_context *ctx, const char *path);
+int spath_raytracer_restore(spath_raytracer_context *ctx, const char *path);
 void spath_raytracer_fill_buffers(spath_raytracer_context *ctx, rt_spath_buffers *out);
 void spath_raytracer_destroy(spath_raytracer_context *ctx);   /* the reference never releases its buffers */
 

@@ -202,7 +202,7 @@ EXPORTED_SYMBOLS = [
     "init_ss_raytracer_context", "ss_raytracer_render", "ss_raytracer_prepass",
     "init_path_raytracer_context", "path_raytracer_render", "path_raytracer_prepass",
     "init_spath_raytracer_context", "spath_raytracer_render", "spath_raytracer_prepass",
-    "spath_raytracer_ray_test", "spath_raytracer_kd_test",
+    "spath_raytracer_ray_test", "spath_raytracer_kd_test", "spath_raytracer_save", "spath_raytracer_restore",
     "spath_raytracer_resolve", "spath_raytracer_flush", "spath_raytracer_fill_buffers", "spath_raytracer_calibrate",
     "ss_raytracer_destroy", "path_raytracer_destroy", "spath_raytracer_destroy",
 ]
@@ -311,6 +311,9 @@ def lib():
     for f in ("spath_raytracer_render", "spath_raytracer_prepass", "spath_raytracer_resolve", "spath_raytracer_flush",
               "spath_raytracer_calibrate", "spath_raytracer_ray_test", "spath_raytracer_kd_test"):
         getattr(L, f).argtypes = [C.POINTER(spath_raytracer_context)]
+    for f in ("spath_raytracer_save", "spath_raytracer_restore"):
+        getattr(L, f).restype = C.c_int
+        getattr(L, f).argtypes = [C.POINTER(spath_raytracer_context), C.c_char_p]
     L.spath_raytracer_fill_buffers.argtypes = [C.POINTER(spath_raytracer_context), C.POINTER(rt_spath_buffers)]
     L.spath_raytracer_destroy.argtypes = [C.POINTER(spath_raytracer_context)]
     L.path_raytracer_destroy.argtypes = [C.POINTER(path_raytracer_context)]

@@ -431,6 +431,122 @@ void spath_raytracer_render(spath_raytracer_context *c)
     }
 }
 
+/* ---- checkpoint / resume ------------------------------------------------------------------------------------ */
+typedef struct {
+    char     magic[8];                 /* "RTSPATH1" */
+    uint32_t width, height;            /* local frame of the context */
+    rt_rows  rows;                     /* which rows of the full frame they are */
+    uint32_t num_tris, tree_bytes;     /* the scene the state belongs to */
+    uint32_t iteration;                /* iterations the buffers have been through */
+    uint32_t num_iterations;
+    int32_t  rng_mode;
+    uint32_t rng_seed, rng_launch;
+    uint32_t reserved[4];
+} spath_checkpoint_header;
+
+#define RT_CHECKPOINT_BUFFERS 10
+static void checkpoint_buffers(spath_raytracer_context *c, rt_mem mem[RT_CHECKPOINT_BUFFERS], size_t bytes[RT_CHECKPOINT_BUFFERS])
+{
+    rt_spath_buffers b;
+    spath_raytracer_fill_buffers(c, &b);
+    const rt_mem m[RT_CHECKPOINT_BUFFERS] = { b.ray_o, b.ray_d, b.origin_o, b.origin_d, b.hits, b.source_hits, b.prog_a,
+                                               b.prog_b, b.random, b.out_tex };
+    for (int k = 0; k < RT_CHECKPOINT_BUFFERS; k++) { mem[k] = m[k]; bytes[k] = 16; }
+    bytes[8] = 4;
+}
+
+static void checkpoint_header(spath_raytracer_context *c, spath_checkpoint_header *hd)
+{
+    raytracer_context *rctx = c->rctx;
+    memset(hd, 0, sizeof *hd);
+    memcpy(hd->magic, "RTSPATH1", 8);
+    hd->width = rctx->width;
+    hd->height = rctx->height;
+    raytracer_get_rows(rctx, &hd->rows);
+    hd->num_tris = rctx->stat_scene->kdt->view.num_tris;
+    hd->tree_bytes = rctx->stat_scene->kdt->buffer_size;
+    hd->iteration = c->launched_upto;
+    hd->num_iterations = c->num_iterations;
+    hd->rng_mode = c->rng_mode;
+    hd->rng_seed = c->rng_seed;
+    hd->rng_launch = c->rng_launch;
+}
+
+int spath_raytracer_save(spath_raytracer_context *c, const char *path)
+{
+    rt_device *dev = c->rctx->rcl->device;
+    const size_t n = (size_t)c->rctx->width * c->rctx->height;
+    spath_raytracer_flush(c);
+    rt_device_sync(dev);
+    FILE *f = fopen(path, "wb");
+    if (!f) { fprintf(stderr, "spath_raytracer_save: cannot write %s\n", path); return 1; }
+    spath_checkpoint_header hd;
+    checkpoint_header(c, &hd);
+    rt_mem mem[RT_CHECKPOINT_BUFFERS];
+    size_t bytes[RT_CHECKPOINT_BUFFERS];
+    checkpoint_buffers(c, mem, bytes);
+    void *host = malloc(16 * (n ? n : 1));
+    int bad = fwrite(&hd, sizeof hd, 1, f) != 1;
+    for (int k = 0; k < RT_CHECKPOINT_BUFFERS && !bad; k++) {
+        rt_mem_download(dev, host, mem[k], bytes[k] * n);
+        bad = n && fwrite(host, bytes[k], n, f) != n;
+    }
+    free(host);
+    if (fclose(f) != 0) bad = 1;
+    if (bad) { fprintf(stderr, "spath_raytracer_save: writing %s failed\n", path); remove(path); return 2; }
+    return 0;
+}
+
+int spath_raytracer_restore(spath_raytracer_context *c, const char *path)
+{
+    rt_device *dev = c->rctx->rcl->device;
+    const size_t n = (size_t)c->rctx->width * c->rctx->height;
+    FILE *f = fopen(path, "rb");
+    if (!f) { fprintf(stderr, "spath_raytracer_restore: cannot read %s\n", path); return 1; }
+    spath_checkpoint_header hd, mine;
+    checkpoint_header(c, &mine);
+    rt_mem mem[RT_CHECKPOINT_BUFFERS];
+    size_t bytes[RT_CHECKPOINT_BUFFERS], total = sizeof hd;
+    checkpoint_buffers(c, mem, bytes);
+    for (int k = 0; k < RT_CHECKPOINT_BUFFERS; k++) total += bytes[k] * n;
+    int bad = fread(&hd, sizeof hd, 1, f) != 1 || memcmp(hd.magic, mine.magic, 8) != 0;
+    if (!bad)
+        bad = hd.width != mine.width || hd.height != mine.height || memcmp(&hd.rows, &mine.rows, sizeof hd.rows) != 0 ||
+              hd.num_tris != mine.num_tris || hd.tree_bytes != mine.tree_bytes;
+    if (!bad) { fseek(f, 0, SEEK_END); bad = (size_t)ftell(f) != total; fseek(f, (long)sizeof hd, SEEK_SET); }
+    if (bad) {
+        fprintf(stderr, "spath_raytracer_restore: %s is not a checkpoint of this frame and scene\n", path);
+        fclose(f);
+        return 2;
+    }
+    /* everything is read before anything is changed */
+    void *host[RT_CHECKPOINT_BUFFERS] = { 0 };
+    for (int k = 0; k < RT_CHECKPOINT_BUFFERS && !bad; k++) {
+        host[k] = malloc(bytes[k] * (n ? n : 1));
+        bad = n && fread(host[k], bytes[k], n, f) != n;
+    }
+    fclose(f);
+    if (!bad) {
+        spath_raytracer_flush(c);
+        rt_device_sync(dev);
+        for (int k = 0; k < RT_CHECKPOINT_BUFFERS; k++) rt_mem_upload(dev, mem[k], host[k], bytes[k] * n);
+        c->current_iteration = c->launched_upto = hd.iteration;
+        c->num_iterations = hd.num_iterations;
+        c->rng_mode = hd.rng_mode;
+        c->rng_seed = hd.rng_seed;
+        c->rng_launch = hd.rng_launch;
+        c->render_complete = false;
+        c->pending = 0;
+        c->snap_count = 0;
+        c->snap_first_iteration = 0;
+        c->order_valid = false;             /* costs of the restored pixels are not known to this context */
+    } else {
+        fprintf(stderr, "spath_raytracer_restore: reading %s failed\n", path);
+    }
+    for (int k = 0; k < RT_CHECKPOINT_BUFFERS; k++) free(host[k]);
+    return bad ? 3 : 0;
+}
+
 void spath_raytracer_destroy(spath_raytracer_context *c)
 {
     if (!c) return;

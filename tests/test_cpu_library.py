@@ -75,3 +75,20 @@ def test_no_product_import_of_the_oracle():
             if f.endswith((".py", ".c", ".h", ".hpp", ".hip")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in text and "from oracle" not in text and "oracle_rt" not in text, f
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """`python bench.py --gpus N` run plainly starts its own ranks -- after checking, without touching a GPU, that N
+    are visible.  With fewer (none in a CPU container) it exits non-zero with a message and prints no result line."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "RT_BENCH_SHARE_GPU")}
+    import torch
+    if torch.cuda.device_count() >= 64:
+        return
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "64", "--workload", "tiny"], cwd=root,
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode != 0 and not p.stdout.strip()
+    assert b"GPU(s) are visible" in p.stderr

@@ -432,3 +432,67 @@ def test_traversal_against_frozen_outputs_of_the_reference_kernel(rt):
     for m in (ro, rd, hits):
         r.L.rt_mem_free(r.dev, m)
     r.close()
+
+
+def test_second_prepass_starts_a_fresh_render(rt, orc, small):
+    """A context that has rendered (launches that ran ahead, snapshots taken, pixel order learnt) and is given a new
+    prepass renders exactly what a fresh context renders: nothing of the first render's launch state survives."""
+    sc, tree = small
+    w, h, seed, every = 256, 256, 23, 4
+    r = rt.Renderer(sc, w, h).build()
+    r.init_spath(seed=seed, resolve_interval=every)
+    r.spath_prepass(num_iterations=11)
+    r.spath_render(11)
+    first = r.spath_state()["out_tex"].copy()
+    r.spath_prepass(num_iterations=6)             # restarts the random streams of the seeded mode as well
+    frames = []
+    for k in range(1, 7):
+        r.L.spath_raytracer_render(r.spath)
+        if k % every == 0:
+            frames.append(r.output.copy())
+    again = r.spath_state()
+    c = r.spath.contents
+    assert c.launches == 1 and c.launched_upto == 6 and c.current_iteration == 6
+    r.close()
+    st = oracle_spath_run(orc, sc, tree, w, h, seed, 4)
+    assert_bits_equal(frames[0], st.resolve(), "frame at call 4 of the second render")
+    for k in range(2):
+        st.iterate(int(rt.scenes.splitmix32(seed + 1, np.arange(7, dtype=np.uint64))[5 + k]))
+    assert_bits_equal(again["out_tex"], st.out_tex, "out_tex of the second render")
+    assert_bits_equal(again["progress"], st.progress, "progress of the second render")
+    assert not np.array_equal(first, again["out_tex"])
+
+
+def test_checkpoint_and_resume(rt, orc, small, tmp_path):
+    """10 iterations, save, a new context on the same scene, restore, 6 more: every per-pixel buffer equals the
+    uninterrupted 16-iteration render's (the oracle's), bit for bit; a checkpoint of another frame size is refused."""
+    sc, tree = small
+    w, h, seed = 96, 64, 29
+    path = str(tmp_path / "render.ckpt").encode()
+    a = rt.Renderer(sc, w, h).build()
+    a.init_spath(seed=seed, resolve_interval=0)
+    a.spath_prepass(num_iterations=16)
+    a.spath_render(10)
+    assert a.L.spath_raytracer_save(a.spath, path) == 0
+    a.close()
+    b = rt.Renderer(sc, w, h).build()
+    b.init_spath(seed=seed + 100, resolve_interval=0)        # the checkpoint brings its own seed and stream position
+    b.spath_prepass(num_iterations=3)
+    assert b.L.spath_raytracer_restore(b.spath, path) == 0
+    assert b.spath.contents.current_iteration == 10 and b.spath.contents.num_iterations == 16
+    b.spath_render(6)
+    g = b.spath_state()
+    img = b.spath_resolve()
+    b.close()
+    st = oracle_spath_run(orc, sc, tree, w, h, seed, 16)
+    hits_equal(g["results"], st.results, "bounce hits")
+    for name in ("rays", "origin_rays", "progress", "random", "out_tex"):
+        assert_bits_equal(g[name], getattr(st, name), name)
+    assert_bits_equal(img, st.resolve(), "resolved frame")
+    c = rt.Renderer(sc, w, h + 8).build()
+    c.init_spath(seed=seed, resolve_interval=0)
+    c.spath_prepass(num_iterations=3)
+    assert c.L.spath_raytracer_restore(c.spath, path) == 2
+    assert c.L.spath_raytracer_restore(c.spath, b"/nonexistent/file") == 1
+    assert c.spath.contents.current_iteration == 0
+    c.close()
