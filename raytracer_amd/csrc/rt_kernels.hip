@@ -1626,6 +1626,8 @@ void rt_k_spath_run_snap(rt_device *dev, const rt_kd_view *kd, const rt_spath_bu
     B.cost = (uint32_t *)cost;
     B.order = (const uint32_t *)order;
     B.snap = (float4 *)snapshots;
+    // the lanes count down to the next snapshot in 16 bits: an interval longer than a launch can be never comes round again
+    if (snap_every > 0xffffu) snap_every = 0xffffu;
     if (!cost) { fprintf(stderr, "ERROR: rt_k_spath_run needs a per-pixel cost buffer\n"); exit(1); }
     launch_spath_run(dev, P, B, n, iters, (const uint32_t *)random_values, schedule, snap_first, snap_every);
 }
