@@ -70,6 +70,7 @@ typedef struct kd_tree_flat {
     uint32_t  num_leaf_slots;
     uint32_t  root_ref;
     uint32_t  max_depth;    /* interior nodes on the longest root-to-leaf path */
+    uint32_t  plain_splits; /* 1: every split position is 0 or 2^-16 <= |b| <= 2^39 (rt_kd_view.plain_splits) */
 } kd_tree_flat;
 
 /* reference: include/kdtree.h:65-91 */

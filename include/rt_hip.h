@@ -129,6 +129,11 @@ typedef struct rt_kd_view {
     float scene_max[3];
     uint32_t max_depth;      /* interior nodes on the longest root-to-leaf path: bounds the traversal stack; the
                                 launches refuse a view with max_depth >= RT_MAX_STACK */
+    uint32_t plain_splits;   /* 1: every split position is 0 or has 2^-16 <= |b| <= 2^39 (kd_tree_flatten checks): the
+                                walk may then compute its plane distances (b - o) / d for rays whose origin and
+                                direction components are in like ranges as (b - o) * RN(1/d) corrected by two fused
+                                multiply-adds, which is the correctly rounded quotient in those ranges; 0: always the
+                                division.  Results are the same either way */
 } rt_kd_view;
 
 /* Original (un-flattened) scene arrays for the brute-force integrators

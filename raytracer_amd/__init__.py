@@ -56,14 +56,15 @@ class AABB(C.Structure):
 
 class kd_tree_flat(C.Structure):
     _fields_ = [("nodes", C.POINTER(C.c_uint32)), ("leaf_tris", C.POINTER(C.c_float)), ("num_nodes", C.c_uint32),
-                ("num_leaf_slots", C.c_uint32), ("root_ref", C.c_uint32), ("max_depth", C.c_uint32)]
+                ("num_leaf_slots", C.c_uint32), ("root_ref", C.c_uint32), ("max_depth", C.c_uint32),
+                ("plain_splits", C.c_uint32)]
 
 
 class rt_kd_view(C.Structure):
     _fields_ = [("nodes", C.c_void_p), ("leaf_tris", C.c_void_p), ("tri_shade", C.c_void_p),
                 ("num_nodes", C.c_uint32), ("num_leaf_slots", C.c_uint32), ("num_tris", C.c_uint32),
                 ("root_ref", C.c_uint32), ("scene_min", C.c_float * 3), ("scene_max", C.c_float * 3),
-                ("max_depth", C.c_uint32)]
+                ("max_depth", C.c_uint32), ("plain_splits", C.c_uint32)]
 
 
 class rt_spath_buffers(C.Structure):

@@ -447,6 +447,7 @@ typedef struct flat_ctx {
     const float (*verts)[4];
     const int (*idx)[4];
     uint32_t next_node, next_slot, depth_max;
+    int plain_splits;
 } flat_ctx;
 
 static uint32_t flatten_leaf(flat_ctx *fc, const kd_tree_node *n)
@@ -473,6 +474,12 @@ static uint32_t flatten_rec(flat_ctx *fc, const kd_tree_node *n, uint32_t depth)
 {
     if (depth > fc->depth_max) fc->depth_max = depth;
     if (!n->left) return flatten_leaf(fc, n);
+    {   /* rt_kd_view.plain_splits: 0, or 2^-16 <= |b| <= 2^39 (exponent fields 111..166) */
+        uint32_t bits;
+        memcpy(&bits, &n->b, 4);
+        bits &= 0x7fffffffu;
+        if (bits != 0 && (bits < 0x37800000u || bits > 0x53000000u)) fc->plain_splits = 0;
+    }
     const uint32_t self = fc->next_node++;
     uint32_t rec[8] = {0};
     uint32_t packed = (uint32_t)(n->k > 2 ? 2 : n->k);
@@ -517,10 +524,12 @@ void kd_tree_flatten(kd_tree *tree)
     fc.verts = (const float (*)[4])tree->s->mesh_verts;
     fc.idx = (const int (*)[4])tree->s->mesh_indices;
     fc.next_node = fc.next_slot = fc.depth_max = 0;
+    fc.plain_splits = 1;
     f->root_ref = flatten_rec(&fc, tree->root, 0);
     f->num_nodes = fc.next_node;
     f->nodes = (uint32_t *)realloc(f->nodes, sizeof(uint32_t) * 8 * (size_t)(f->num_nodes ? f->num_nodes : 1));
     f->max_depth = fc.depth_max;
+    f->plain_splits = (uint32_t)fc.plain_splits;
     if (fc.depth_max >= RT_MAX_STACK) {        /* a ray pushes at most one entry per level */
         fprintf(stderr, "ERROR: kd-tree depth %u exceeds the traversal stack\n", fc.depth_max);
         exit(1);

@@ -168,6 +168,7 @@ struct TravScene {
     const float4 *leaf_tris;
     f3 smin, smax;
     uint32_t root_ref;
+    uint32_t plain_splits;       // rt_kd_view.plain_splits
 };
 
 // Registers of one lane's walk (the ray itself, o and d, stays in plain locals
@@ -190,11 +191,27 @@ __device__ __forceinline__ void walk_enter(Walk &w, uint32_t ref)
 // (getTBoundingBox, reference: src/kernels/collision.cl:71-86) and the first
 // pass of the reference's outer loop.  false = the walk is over before it
 // starts (the ray misses the box): the result is a miss.
-__device__ __forceinline__ bool walk_begin(const TravScene &P, Walk &w, f3 o, f3 d)
+// Also sets what the descend steps use to divide by the ray's direction: rd = the correctly rounded reciprocals of
+// d's components, and `plain` = every component of the ray is in the range in which (b - o) * rd, corrected by two
+// fused multiply-adds, is the correctly rounded (b - o) / d (see walk_descend) and the tree's splits are too.
+__device__ __forceinline__ bool in_exponent_range(float x, uint32_t lo_bits, uint32_t hi_bits)
+{
+    return ((__float_as_uint(x) & 0x7fffffffu) - lo_bits) <= (hi_bits - lo_bits);
+}
+
+__device__ __forceinline__ bool walk_begin(const TravScene &P, Walk &w, f3 o, f3 d, f3 &rd, bool &plain)
 {
     float scene_t_min = 0.f;
     w.scene_t_max = RT_INF;
     f3 inv = mk3(1 / d.x, 1 / d.y, 1 / d.z);
+    rd = inv;
+    // origin components: 0 or 2^-16 <= |o| <= 2^39; direction components: 2^-30 <= |d| <= 2^30
+    const bool ox = (o.x == 0.f) | in_exponent_range(o.x, 0x37800000u, 0x53000000u);
+    const bool oy = (o.y == 0.f) | in_exponent_range(o.y, 0x37800000u, 0x53000000u);
+    const bool oz = (o.z == 0.f) | in_exponent_range(o.z, 0x37800000u, 0x53000000u);
+    const bool dx = in_exponent_range(d.x, 0x30800000u, 0x4e800000u), dy = in_exponent_range(d.y, 0x30800000u, 0x4e800000u),
+               dz = in_exponent_range(d.z, 0x30800000u, 0x4e800000u);
+    plain = (int)ox & (int)oy & (int)oz & (int)dx & (int)dy & (int)dz & (int)(P.plain_splits != 0u);
     f3 t0 = (P.smin - o) * inv, t1 = (P.smax - o) * inv;
     f3 sm = mk3(cl_min(t0.x, t1.x), cl_min(t0.y, t1.y), cl_min(t0.z, t1.z));
     f3 bg = mk3(cl_max(t0.x, t1.x), cl_max(t0.y, t1.y), cl_max(t0.z, t1.z));
@@ -227,12 +244,31 @@ __device__ __forceinline__ void undefined_words(uint4 &x)
 // (left, right), reference: src/kernels/kdtree.cl:229-260.  get_elem (:67-75)
 // adds the masked-out zeros, which turns -0 into +0.
 template <int LDS_DEPTH>
-__device__ __forceinline__ void walk_descend(Walk &w, f3 o, f3 d, uint32_t k, float b, uint32_t left, uint32_t right,
-                                             uint2 *__restrict__ col, uint2 *__restrict__ spill, bool en)
+__device__ __forceinline__ void walk_descend(Walk &w, f3 o, f3 d, f3 rd, bool plain, uint32_t k, float b, uint32_t left,
+                                             uint32_t right, uint2 *__restrict__ col, uint2 *__restrict__ spill, bool en)
 {
     const float ok = ((k == 0) ? o.x : ((k == 1) ? o.y : o.z)) + 0.0f;
     const float dk = ((k == 0) ? d.x : ((k == 1) ? d.y : d.z)) + 0.0f;
-    const float t_split = (b - ok) / dk;
+    // t_split = (b - ok) / dk, correctly rounded.  With y = RN(1/dk) kept per ray: q = RN(num * y) is within an ulp
+    // of the quotient, rem = num - q * dk is exact in one fused multiply-add, and RN(q + rem * y) is the correctly
+    // rounded quotient (Markstein's division by a correctly rounded reciprocal) as long as nothing underflows or
+    // overflows on the way -- which the ranges behind `plain` rule out: dk in 2^-30..2^30; num = b - ok is 0 or in
+    // 2^-40..2^40 because b and ok are each 0 or in 2^-16..2^39.  (A zero quotient may come out with the other
+    // sign; t_split is only ever compared.)  Five instructions for the division's eleven.  Lanes that are not
+    // `plain` (axis-parallel and null rays, origins within 1.5e-5 of a coordinate plane) divide.
+    const float num = b - ok;
+#ifdef RT_ALWAYS_DIVIDE      /* A/B builds: the division for every lane */
+    const float t_split = num / dk;
+#else
+    const float rk = (k == 0) ? rd.x : ((k == 1) ? rd.y : rd.z);
+    const float q = num * rk;
+    const float rem = __builtin_fmaf(-q, dk, num);
+    float t_split = __builtin_fmaf(rem, rk, q);
+    if (__any(en & !plain)) {
+        const float exact = num / dk;
+        t_split = plain ? t_split : exact;
+    }
+#endif
     const bool left_close = (ok < b) | ((ok == b) & (dk <= 0));
     const uint32_t first = left_close ? left : right;
     const uint32_t second = left_close ? right : left;
@@ -255,7 +291,7 @@ __device__ __forceinline__ void walk_descend(Walk &w, f3 o, f3 d, uint32_t k, fl
 // on one of its nodes: from the record's top through one of its children when that child is interior too, so up
 // to two levels; a lane that stands on a child position (popped from the stack) takes one.
 template <int LDS_DEPTH>
-__device__ __forceinline__ void walk_record_steps(Walk &w, f3 o, f3 d, const uint4 &a, const uint4 &r,
+__device__ __forceinline__ void walk_record_steps(Walk &w, f3 o, f3 d, f3 rd, bool plain, const uint4 &a, const uint4 &r,
                                                   uint2 *__restrict__ col, uint2 *__restrict__ spill, bool en)
 {
     const uint32_t top = w.ref & ~3u;                    // reference of the record's top = record index * 4
@@ -263,19 +299,19 @@ __device__ __forceinline__ void walk_record_steps(Walk &w, f3 o, f3 d, const uin
     const bool en1 = en & ((w.ref & 3u) == 0u);
     const uint32_t left = (packed & 64u) ? r.x : (top | 1u);
     const uint32_t right = (packed & 128u) ? r.z : (top | 2u);
-    walk_descend<LDS_DEPTH>(w, o, d, packed & 3u, __uint_as_float(a.x), left, right, col, spill, en1);
+    walk_descend<LDS_DEPTH>(w, o, d, rd, plain, packed & 3u, __uint_as_float(a.x), left, right, col, spill, en1);
     // now at a leaf or at a child position of this record (never at another record's top)
     const bool en2 = en & !(w.ref & RT_REF_LEAF) & ((w.ref & 3u) != 0u);
     const bool at_left = (w.ref & 3u) == 1u;
-    walk_descend<LDS_DEPTH>(w, o, d, (packed >> (at_left ? 2 : 4)) & 3u, __uint_as_float(at_left ? a.y : a.z),
+    walk_descend<LDS_DEPTH>(w, o, d, rd, plain, (packed >> (at_left ? 2 : 4)) & 3u, __uint_as_float(at_left ? a.y : a.z),
                             at_left ? r.x : r.z, at_left ? r.y : r.w, col, spill, en2);
 }
 
 // Lanes with `en` stand on an interior node: fetch its two-level record (32
 // bytes) and descend.
 template <int LDS_DEPTH>
-__device__ __forceinline__ void walk_interior(const TravScene &P, Walk &w, f3 o, f3 d, uint2 *__restrict__ col,
-                                              uint2 *__restrict__ spill, bool en)
+__device__ __forceinline__ void walk_interior(const TravScene &P, Walk &w, f3 o, f3 d, f3 rd, bool plain,
+                                              uint2 *__restrict__ col, uint2 *__restrict__ spill, bool en)
 {
     uint4 a, r;
     undefined_words(a); undefined_words(r);
@@ -286,7 +322,7 @@ __device__ __forceinline__ void walk_interior(const TravScene &P, Walk &w, f3 o,
     // both halves are fetched here, together: left alone, the compiler sinks the
     // words only the first step needs into that step, as a second round trip
     asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(r.x), "+v"(r.y), "+v"(r.z), "+v"(r.w));
-    walk_record_steps<LDS_DEPTH>(w, o, d, a, r, col, spill, en);
+    walk_record_steps<LDS_DEPTH>(w, o, d, rd, plain, a, r, col, spill, en);
 }
 
 // What leaving a leaf delivers (src/kernels/kdtree.cl:205-226): entry sp-1 of the stack -- the far child kept
@@ -402,8 +438,9 @@ __device__ __forceinline__ bool walk_leaf_load(const TravScene &P, Walk &w, f3 o
 // round trip, where fetching records and triangles in two slots takes two dependent round trips per trip.  The
 // decisions are those of walk_descend / walk_leaf_step, so results do not depend on which form runs.
 template <int LDS_DEPTH>
-__device__ __forceinline__ bool walk_trip_fused(const TravScene &P, Walk &w, f3 o, f3 d, uint2 *__restrict__ col,
-                                                uint2 *__restrict__ spill, bool walking, uint32_t &steps)
+__device__ __forceinline__ bool walk_trip_fused(const TravScene &P, Walk &w, f3 o, f3 d, f3 rd, bool plain,
+                                                uint2 *__restrict__ col, uint2 *__restrict__ spill, bool walking,
+                                                uint32_t &steps)
 {
     const bool in_leaf = walking & ((w.ref & RT_REF_LEAF) != 0u);
     const bool in_node = walking & !(w.ref & RT_REF_LEAF);
@@ -439,7 +476,7 @@ __device__ __forceinline__ bool walk_trip_fused(const TravScene &P, Walk &w, f3 
     const float4 T2 = make_float4(__uint_as_float(t2.x), __uint_as_float(t2.y), __uint_as_float(t2.z), __uint_as_float(t2.w));
     bool moved;
     const bool fin = walk_leaf_step<LDS_DEPTH>(P, w, o, d, T0, T1, T2, pd, in_leaf, has, moved);
-    walk_record_steps<LDS_DEPTH>(w, o, d, a, r, col, spill, in_node | (moved & ahead));
+    walk_record_steps<LDS_DEPTH>(w, o, d, rd, plain, a, r, col, spill, in_node | (moved & ahead));
     return fin;
 }
 
@@ -492,8 +529,8 @@ __global__ __launch_bounds__(64) void k_kd_intersect(TravScene P, const float4 *
 
     WorkQueue q;
     Walk w = {};
-    f3 o = mk3(0.f, 0.f, 0.f), d = o;
-    bool walking = false;
+    f3 o = mk3(0.f, 0.f, 0.f), d = o, rd = o;
+    bool walking = false, plain = false;
     uint32_t ridx = 0;
 
     for (;;) {
@@ -505,7 +542,7 @@ __global__ __launch_bounds__(64) void k_kd_intersect(TravScene P, const float4 *
                 ridx = mine;
                 o = xyz(ray_o[ridx]);
                 d = xyz(ray_d[ridx]);
-                walking = walk_begin(P, w, o, d);
+                walking = walk_begin(P, w, o, d, rd, plain);
                 if (!walking) hits[ridx] = walk_result(w);
             }
         }
@@ -515,7 +552,7 @@ __global__ __launch_bounds__(64) void k_kd_intersect(TravScene P, const float4 *
         }
         if (FUSED) {
             uint32_t steps = 0;
-            if (walk_trip_fused<LDS_DEPTH>(P, w, o, d, col, spill, walking, steps)) {
+            if (walk_trip_fused<LDS_DEPTH>(P, w, o, d, rd, plain, col, spill, walking, steps)) {
                 hits[ridx] = walk_result(w);
                 walking = false;
             }
@@ -524,7 +561,7 @@ __global__ __launch_bounds__(64) void k_kd_intersect(TravScene P, const float4 *
         // one record (up to two descend steps) for the lanes on interior nodes,
         // then one triangle for the lanes in leaves
         const bool in_node = walking & !(w.ref & RT_REF_LEAF);
-        if (__any(in_node)) walk_interior<LDS_DEPTH>(P, w, o, d, col, spill, in_node);
+        if (__any(in_node)) walk_interior<LDS_DEPTH>(P, w, o, d, rd, plain, col, spill, in_node);
         const bool in_leaf = walking & ((w.ref & RT_REF_LEAF) != 0u);
         if (__any(in_leaf)) {
             if (walk_leaf_load<LDS_DEPTH>(P, w, o, d, col, spill, in_leaf)) {
@@ -781,7 +818,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
     enum { FREE = 0, WALK = 1, DONE = 2 };
     WorkQueue q;
     Walk w = {};
-    f3 o = mk3(0.f, 0.f, 0.f), d = o;
+    f3 o = mk3(0.f, 0.f, 0.f), d = o, rd = o;
+    bool plain = false;
     uint32_t mode = FREE, pix = 0, it = 0, rnd = 0, steps = 0;
 #ifdef RT_WAVE_TIMES
     if (threadIdx.x == 0 && blockIdx.x < 16384) B.cost[n + 4 * blockIdx.x] = (uint32_t)__builtin_amdgcn_s_memrealtime();
@@ -842,7 +880,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                 fresh = true;
             }
             // (c) start the walk of every new ray
-            if (fresh) mode = walk_begin(P, w, o, d) ? WALK : DONE;
+            if (fresh) mode = walk_begin(P, w, o, d, rd, plain) ? WALK : DONE;
         }
 #ifdef RT_WAVE_TIMES
         trips++;
@@ -853,7 +891,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
             continue;
         }
         if (NI == 0) {       // one round trip per trip: walk_trip_fused
-            const bool fin = walk_trip_fused<LDS_DEPTH>(P, w, o, d, col, spill, mode == WALK, steps);
+            const bool fin = walk_trip_fused<LDS_DEPTH>(P, w, o, d, rd, plain, col, spill, mode == WALK, steps);
             mode = fin ? (uint32_t)DONE : mode;
             continue;
         }
@@ -865,7 +903,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
             const bool in_node = (mode == WALK) & !(w.ref & RT_REF_LEAF);
             if (!SKIP_EMPTY || __any(in_node)) {
                 steps += in_node ? 1u : 0u;
-                walk_interior<LDS_DEPTH>(P, w, o, d, col, spill, in_node);
+                walk_interior<LDS_DEPTH>(P, w, o, d, rd, plain, col, spill, in_node);
             }
         }
 #pragma unroll
@@ -1486,6 +1524,7 @@ void rt_k_kd_intersect(rt_device *dev, const rt_kd_view *kd, rt_mem ray_o, rt_me
     P.smin = host3(kd->scene_min);
     P.smax = host3(kd->scene_max);
     P.root_ref = kd->root_ref;
+    P.plain_splits = kd->plain_splits;
     launch_kd_intersect(dev, P, (const float4 *)ray_o, (const float4 *)ray_d, (Hit *)hits, n);
 }
 
@@ -1508,6 +1547,7 @@ int rt_k_kd_intersect_noalloc(rt_device *dev, const rt_kd_view *kd, rt_mem ray_o
     P.smin = host3(kd->scene_min);
     P.smax = host3(kd->scene_max);
     P.root_ref = kd->root_ref;
+    P.plain_splits = kd->plain_splits;
     RT_HIP_CHECK(hipSetDevice(dev->ordinal));
     unsigned grid = (unsigned)dev->noalloc_blocks_per_cu * (unsigned)dev->props.multiProcessorCount;
     const unsigned need = blocks_for(n, 64);
@@ -1617,6 +1657,7 @@ void rt_k_spath_run_snap(rt_device *dev, const rt_kd_view *kd, const rt_spath_bu
     P.smin = host3(kd->scene_min);
     P.smax = host3(kd->scene_max);
     P.root_ref = kd->root_ref;
+    P.plain_splits = kd->plain_splits;
     SpathDev B;
     B.tri_shade = (const float4 *)kd->tri_shade;
     B.out_tex = (float4 *)b->out_tex; B.ray_o = (float4 *)b->ray_o; B.ray_d = (float4 *)b->ray_d;

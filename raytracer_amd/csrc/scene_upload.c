@@ -123,6 +123,7 @@ void scene_resource_push(raytracer_context *rctx)
         kdt->view.num_tris = num_tris;
         kdt->view.root_ref = kdt->flat.root_ref;
         kdt->view.max_depth = kdt->flat.max_depth;
+        kdt->view.plain_splits = kdt->flat.plain_splits;
         for (int k = 0; k < 3; k++) {
             kdt->view.scene_min[k] = through_percent_f(kdt->bounds.min[k]);
             kdt->view.scene_max[k] = through_percent_f(kdt->bounds.max[k]);

@@ -92,3 +92,17 @@ def test_bench_refuses_more_ranks_than_gpus():
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert p.returncode != 0 and not p.stdout.strip()
     assert b"GPU(s) are visible" in p.stderr
+
+
+def test_plane_distance_by_reciprocal_is_the_correctly_rounded_quotient(tmp_path):
+    """The kernels compute (b - o) / d for most rays as (b - o) * RN(1/d) corrected by two fused multiply-adds
+    (rt_kernels.hip: walk_descend).  tests/tools/check_plane_distance_division.c checks that identity against the
+    division on random operands; here 2e8 of them (the committed figure is 6e10 with none wrong)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "check")
+    subprocess.check_call(["gcc", "-O2", "-fopenmp", "-ffp-contract=off", "-mfma",
+                           os.path.join(root, "tests", "tools", "check_plane_distance_division.c"), "-o", exe, "-lm"])
+    out = subprocess.run([exe, "200000000"], stdout=subprocess.PIPE, timeout=300).stdout.decode()
+    assert "bad=0" in out, out
