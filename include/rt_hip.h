@@ -219,7 +219,7 @@ void rt_k_xorshift(rt_device *dev, rt_mem random, uint32_t n);
    (the loop body of src/spath_raytracer.c:364-385 repeated).  random_values is a
    device array of iters words: the random_value of each iteration, in order.
    Buffers end up exactly as iters rounds of the three separate launches leave them.
-   cost (n words, required) receives the number of walk steps each pixel took;
+   cost (n words, required) receives the number of trips of the kernel's loop each pixel was walked in;
    order (n words, or NULL for 0,1,2,...) is the sequence in which pixels are
    handed to lanes -- scheduling only, results do not depend on it.  schedule
    picks how many triangle slots follow the descend slot in each trip of the

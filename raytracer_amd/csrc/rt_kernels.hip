@@ -247,8 +247,11 @@ template <int LDS_DEPTH>
 __device__ __forceinline__ void walk_descend(Walk &w, f3 o, f3 d, f3 rd, bool plain, uint32_t k, float b, uint32_t left,
                                              uint32_t right, uint2 *__restrict__ col, uint2 *__restrict__ spill, bool en)
 {
-    const float ok = ((k == 0) ? o.x : ((k == 1) ? o.y : o.z)) + 0.0f;
-    const float dk = ((k == 0) ? d.x : ((k == 1) ? d.y : d.z)) + 0.0f;
+    // get_elem's "+ 0" (-0 becomes +0) changes nothing that is computed from the origin's component (b - (-0) and
+    // b - (+0) are the same number, and so are the comparisons), and from the direction's only the sign of a
+    // quotient by zero: it is applied where the division is, below
+    const float ok = (k == 0) ? o.x : ((k == 1) ? o.y : o.z);
+    const float dk = (k == 0) ? d.x : ((k == 1) ? d.y : d.z);
     // t_split = (b - ok) / dk, correctly rounded.  With y = RN(1/dk) kept per ray: q = RN(num * y) is within an ulp
     // of the quotient, rem = num - q * dk is exact in one fused multiply-add, and RN(q + rem * y) is the correctly
     // rounded quotient (Markstein's division by a correctly rounded reciprocal) as long as nothing underflows or
@@ -258,14 +261,14 @@ __device__ __forceinline__ void walk_descend(Walk &w, f3 o, f3 d, f3 rd, bool pl
     // `plain` (axis-parallel and null rays, origins within 1.5e-5 of a coordinate plane) divide.
     const float num = b - ok;
 #ifdef RT_ALWAYS_DIVIDE      /* A/B builds: the division for every lane */
-    const float t_split = num / dk;
+    const float t_split = num / (dk + 0.0f);
 #else
     const float rk = (k == 0) ? rd.x : ((k == 1) ? rd.y : rd.z);
     const float q = num * rk;
     const float rem = __builtin_fmaf(-q, dk, num);
     float t_split = __builtin_fmaf(rem, rk, q);
     if (__any(en & !plain)) {
-        const float exact = num / dk;
+        const float exact = num / (dk + 0.0f);
         t_split = plain ? t_split : exact;
     }
 #endif
@@ -789,7 +792,7 @@ struct SpathDev {
     const Hit *source_hits;
     float4 *prog_a, *prog_b;
     uint32_t *random;
-    uint32_t *cost;             // out: walk steps each pixel took in this launch
+    uint32_t *cost;             // out: trips of the loop each pixel was walked in, in this launch
     const uint32_t *order;      // in: pixel to serve as j-th work item (nullptr = j)
     float4 *snap;               // out: copies of out_tex at the launch's resolve points, [slot][pixel]
 };
@@ -897,12 +900,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         }
         // up to NI records (two descend steps each), then up to NT triangles: a
         // lane that reaches its leaf within the trip tests its triangles in the
-        // same trip
+        // same trip.  A pixel's cost is the number of trips it was walked in.
+        steps += (mode == WALK) ? 1u : 0u;
 #pragma unroll
         for (int r = 0; r < NI; r++) {
             const bool in_node = (mode == WALK) & !(w.ref & RT_REF_LEAF);
             if (!SKIP_EMPTY || __any(in_node)) {
-                steps += in_node ? 1u : 0u;
                 walk_interior<LDS_DEPTH>(P, w, o, d, rd, plain, col, spill, in_node);
             }
         }
@@ -910,7 +913,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         for (int r = 0; r < NT; r++) {
             const bool in_leaf = (mode == WALK) & ((w.ref & RT_REF_LEAF) != 0u);
             if (!SKIP_EMPTY || __any(in_leaf)) {
-                steps += in_leaf ? 1u : 0u;
                 const bool fin = walk_leaf_load<LDS_DEPTH>(P, w, o, d, col, spill, in_leaf);
                 mode = fin ? (uint32_t)DONE : mode;
             }
