@@ -287,7 +287,8 @@ __device__ __forceinline__ void walk_descend(Walk &w, f3 o, f3 d, f3 rd, bool pl
     w.t_max = push ? t_split : w.t_max;
     const uint32_t to = (c1 | !c2) ? first : second;
     w.ref = en ? to : w.ref;
-    w.li = en ? 0u : w.li;
+    // w.li needs no reset here: it is 0 whenever a lane stands on an interior node (walk_enter and every pop leave
+    // it 0, only leaf steps count it up), so it is 0 on entering a leaf
 }
 
 // The descend steps a two-level record (words a, r; layout in rt_hip.h) allows the lanes with `en`, which stand
