@@ -496,3 +496,48 @@ def test_checkpoint_and_resume(rt, orc, small, tmp_path):
     assert c.L.spath_raytracer_restore(c.spath, b"/nonexistent/file") == 1
     assert c.spath.contents.current_iteration == 0
     c.close()
+
+
+def test_headless_event_protocol(rt, orc, tmp_path):
+    """rt_headless in script mode replays the reference's UI messages and render-thread loop (src/ui.c:24-98,
+    src/startup.c:118-216): events go through rctx->event_stack last in first out, each switch runs the integrator's
+    prepass, every turn renders once with the current integrator, {"type":2} hands out the serialised kd-tree."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(rt.LIB_PATH), "rt_headless")
+    url = rt.scenes.write_rsc(rt.scenes.icosphere_scene(3), str(tmp_path), "ico3")
+    w, h, samples = 64, 48, 3
+    out = tmp_path / "final.ppm"
+    script = tmp_path / "events.txt"
+    script.write_text("\n".join([
+        '{"type":0}',
+        '{"type":1,"action":{"type":0}}', "turn 1", f"frame {tmp_path / 'ss.ppm'}",
+        '{"type":1,"action":{"type":2}}', '{"type":1,"action":{"type":1}}',      # path is queued last: popped first
+        "turn 1", "turn 1", f"turn {samples * 4}", f"frame {tmp_path / 'spath.ppm'}",
+        '{"type": 2}', '{"type":1,"action":{"type":10}}', "turn 2", ""]))
+    env = dict(os.environ, RT_RNG_SEED="9")
+    p = subprocess.run([exe, str(tmp_path), url, str(w), str(h), str(samples), str(out), "script", str(script)], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert p.returncode == 0, p.stderr.decode()[-1500:] + p.stdout.decode()[-1500:]
+    log = p.stdout.decode()
+    order = [log.index(s) for s in ("Nothing Right Now", "Switching To SS Raytracer", "Switching To Path Tracer",
+                                    "Switching To Split Path Tracer", "GE2 requested k-d tree", "Clearing")]
+    assert order == sorted(order), log
+
+    def pixels(path):
+        raw = open(path, "rb").read()
+        header = f"P6\n{w} {h}\n255\n".encode()
+        rgb = np.frombuffer(raw[len(header):], np.uint8).reshape(h * w, 3).astype(np.uint32)
+        return (rgb[:, 0] << 16) | (rgb[:, 1] << 8) | rgb[:, 2]
+
+    sc = rt.load_scene(url, str(tmp_path))
+    r = rt.Renderer(sc, w, h).build()
+    assert_bits_equal(pixels(tmp_path / "ss.ppm"), r.ss_render() & 0xffffff, "single-sweep frame")
+    r.init_spath(seed=9, resolve_interval=50)
+    r.spath_prepass(num_iterations=samples * 4)
+    r.spath_render(samples * 4 + 1)
+    assert_bits_equal(pixels(tmp_path / "spath.ppm"), r.output & 0xffffff, "split path tracer frame")
+    blob = np.ctypeslib.as_array(r.kdt.buffer, shape=(int(r.kdt.buffer_size),)).copy()
+    r.close()
+    assert_bits_equal(np.fromfile(str(out) + ".kdtree", np.uint8), blob, "serialised kd-tree")
+    assert (pixels(out) == 0x404040).all()          # the clear event's placeholder (os_draw_weird in the reference)
