@@ -65,9 +65,9 @@ typedef struct kd_tree_node {
 /* flattened tree on the host, uploaded by scene_resource_push (layouts: rt_hip.h) */
 typedef struct kd_tree_flat {
     uint32_t *nodes;        /* 8 words per two-level record (layout: rt_hip.h) */
-    float    *leaf_tris;    /* 12 floats per slot */
+    float    *leaf_tris;    /* 64-byte lines of 40-byte triangle slots, every leaf from the start of a line */
     uint32_t  num_nodes;    /* records */
-    uint32_t  num_leaf_slots;
+    uint32_t  num_leaf_lines;
     uint32_t  root_ref;
     uint32_t  max_depth;    /* interior nodes on the longest root-to-leaf path */
     uint32_t  plain_splits; /* 1: every split position is 0 or 2^-16 <= |b| <= 2^39 (rt_kd_view.plain_splits) */

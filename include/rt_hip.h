@@ -103,13 +103,18 @@ void     rt_event_wait(rt_device *dev, rt_event e);     /* the host waits until 
  *                word 6, 7  the same for the right child
  *              A reference is (record index << 2) | position (bit 31 clear;
  *              position 0 = the record's top, 1 / 2 = its left / right child)
- *              or a leaf descriptor (bit 31 set): bits 25..0 = first slot in
- *              leaf_tris, bits 30..26 = triangle count, 31 meaning "31 or more,
- *              read the count from the leaf's first slot".  One fetch serves
+ *              or a leaf descriptor (bit 31 set): bits 25..0 = the leaf's first
+ *              64-byte line in leaf_tris, bits 30..26 = triangle count, 31 meaning
+ *              "31 or more, the leaf begins with a header slot".  One fetch serves
  *              two descend steps and leaves cost no node fetch of their own.
- *   leaf_tris  48 bytes per slot, leaf order (a triangle referenced by several
- *              leaves is stored once per leaf): {v0.xyz, index offset as u32 bits},
- *              {v1-v0, triangle count of the leaf as u32 bits}, {v2-v0, 0}.
+ *   leaf_tris  64-byte lines.  Every leaf starts on a line and holds its triangles
+ *              in consecutive 40-byte slots {v0.xyz, v1-v0, v2-v0, index offset
+ *              as u32}, leaf order (a triangle referenced by several leaves is
+ *              stored once per leaf), padded with zeros to the end of its last
+ *              line: a ray testing the leaf touches the fewest lines its triangles
+ *              fit in.  The header slot of a long leaf is a triangle of zero extent
+ *              (no ray hits it; it is tested like the others) whose last word is
+ *              the leaf's slot count, header included.
  *   tri_shade  64 bytes per triangle, indexed by index offset / 3:
  *              {n0.xyz, colour.r}, {n1.xyz, colour.g}, {n2.xyz, colour.b},
  *              {reflectivity, 0, 0, 0}.
@@ -122,7 +127,7 @@ typedef struct rt_kd_view {
     rt_mem leaf_tris;
     rt_mem tri_shade;
     uint32_t num_nodes;          /* records */
-    uint32_t num_leaf_slots;
+    uint32_t num_leaf_lines;     /* 64-byte lines of leaf_tris */
     uint32_t num_tris;
     uint32_t root_ref;           /* reference of the root (a leaf descriptor for a one-leaf tree) */
     float scene_min[3];      /* SCENE_MIN / SCENE_MAX of src/raytracer.c:53-64 */

@@ -56,13 +56,13 @@ class AABB(C.Structure):
 
 class kd_tree_flat(C.Structure):
     _fields_ = [("nodes", C.POINTER(C.c_uint32)), ("leaf_tris", C.POINTER(C.c_float)), ("num_nodes", C.c_uint32),
-                ("num_leaf_slots", C.c_uint32), ("root_ref", C.c_uint32), ("max_depth", C.c_uint32),
+                ("num_leaf_lines", C.c_uint32), ("root_ref", C.c_uint32), ("max_depth", C.c_uint32),
                 ("plain_splits", C.c_uint32)]
 
 
 class rt_kd_view(C.Structure):
     _fields_ = [("nodes", C.c_void_p), ("leaf_tris", C.c_void_p), ("tri_shade", C.c_void_p),
-                ("num_nodes", C.c_uint32), ("num_leaf_slots", C.c_uint32), ("num_tris", C.c_uint32),
+                ("num_nodes", C.c_uint32), ("num_leaf_lines", C.c_uint32), ("num_tris", C.c_uint32),
                 ("root_ref", C.c_uint32), ("scene_min", C.c_float * 3), ("scene_max", C.c_float * 3),
                 ("max_depth", C.c_uint32), ("plain_splits", C.c_uint32)]
 
@@ -419,7 +419,7 @@ class HostKdTree:
         self.bounds_max = np.array(t.bounds.max[:3], np.float32)
         f = t.flat
         self.nodes = np.ctypeslib.as_array(f.nodes, shape=(max(f.num_nodes, 1), 8)).copy()[:f.num_nodes]
-        self.leaf_tris = np.ctypeslib.as_array(f.leaf_tris, shape=(max(f.num_leaf_slots, 1), 12)).copy()[:f.num_leaf_slots]
+        self.leaf_tris = np.ctypeslib.as_array(f.leaf_tris, shape=(max(f.num_leaf_lines, 1), 16)).copy()[:f.num_leaf_lines]   # 64-byte lines
         self.root_ref = int(f.root_ref)
 
     def __del__(self):

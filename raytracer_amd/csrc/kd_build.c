@@ -442,29 +442,68 @@ void kd_tree_generate_serialized(kd_tree *tree)
 #define REF_SLOT_BITS   26
 #define REF_COUNT_MAX   31u
 
+#define LEAF_SLOT_BYTES 40u
+#define LEAF_LINE_BYTES 64u
+
 typedef struct flat_ctx {
     kd_tree_flat *f;
     const float (*verts)[4];
     const int (*idx)[4];
-    uint32_t next_node, next_slot, depth_max;
+    uint32_t next_node, next_line, cap_lines, depth_max;
+    uint32_t hole, has_hole;        /* a single line left free by an alignment step, for the next one-line leaf */
     int plain_splits;
 } flat_ctx;
 
+/* A leaf's triangles, 40 bytes each, from the start of a 64-byte line of
+ * leaf_tris (layout: rt_hip.h): a ray that tests the leaf touches the fewest
+ * lines the triangles fit in.  A leaf of REF_COUNT_MAX or more triangles
+ * begins with a header slot: a triangle of zero extent, which no ray hits,
+ * carrying the leaf's slot count where the others carry their index offset. */
 static uint32_t flatten_leaf(flat_ctx *fc, const kd_tree_node *n)
 {
     const uint32_t cnt = n->triangles.num_triangles;
-    const uint32_t start = fc->next_slot;
-    for (uint32_t i = 0; i < cnt; i++) {
+    const uint32_t is_long = cnt >= REF_COUNT_MAX;
+    const uint32_t slots = cnt + is_long;
+    const uint32_t lines = (slots * LEAF_SLOT_BYTES + LEAF_LINE_BYTES - 1u) / LEAF_LINE_BYTES;
+    if (cnt == 0) return REF_LEAF;
+    if ((uint64_t)fc->next_line + lines + 1u >= (1u << REF_SLOT_BITS)) {    /* keeps the array below 4 GiB: 32-bit byte offsets */
+        fprintf(stderr, "ERROR: kd-tree too large for the flattened layout (more than %u lines of leaf triangles)\n",
+                1u << REF_SLOT_BITS);
+        exit(1);
+    }
+    if (fc->next_line + lines + 1u > fc->cap_lines) {
+        while (fc->next_line + lines + 1u > fc->cap_lines) fc->cap_lines = fc->cap_lines ? fc->cap_lines * 2u : 1024u;
+        fc->f->leaf_tris = (float *)realloc(fc->f->leaf_tris, (size_t)fc->cap_lines * LEAF_LINE_BYTES);
+    }
+    /* The memory system fetches 128 bytes for the price of 64: a leaf of an even number of lines starts on an
+       even line, so that it lies in lines / 2 such pairs and not one more. */
+    uint32_t start;
+    if (lines == 1u && fc->has_hole) {
+        start = fc->hole;
+        fc->has_hole = 0;
+    } else {
+        if (!(lines & 1u) && (fc->next_line & 1u)) {
+            memset(fc->f->leaf_tris + (size_t)fc->next_line * (LEAF_LINE_BYTES / 4u), 0, LEAF_LINE_BYTES);
+            if (!fc->has_hole) { fc->hole = fc->next_line; fc->has_hole = 1; }
+            fc->next_line++;
+        }
+        start = fc->next_line;
+        fc->next_line += lines;
+    }
+    float *o = fc->f->leaf_tris + (size_t)start * (LEAF_LINE_BYTES / 4u);
+    memset(o, 0, (size_t)lines * LEAF_LINE_BYTES);
+    if (is_long) { memcpy(&o[9], &slots, 4); o += LEAF_SLOT_BYTES / 4u; }
+    for (uint32_t i = 0; i < cnt; i++, o += LEAF_SLOT_BYTES / 4u) {
         const unsigned int off = n->triangles.triangle_buffer[i];
         const float *a = fc->verts[fc->idx[off][0]];
         const float *b = fc->verts[fc->idx[off + 1][0]];
         const float *c = fc->verts[fc->idx[off + 2][0]];
-        float *o = fc->f->leaf_tris + 12 * (size_t)fc->next_slot++;
-        o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; memcpy(&o[3], &off, 4);
-        o[4] = b[0] - a[0]; o[5] = b[1] - a[1]; o[6] = b[2] - a[2]; memcpy(&o[7], &cnt, 4);
-        o[8] = c[0] - a[0]; o[9] = c[1] - a[1]; o[10] = c[2] - a[2]; o[11] = 0.f;
+        o[0] = a[0]; o[1] = a[1]; o[2] = a[2];
+        o[3] = b[0] - a[0]; o[4] = b[1] - a[1]; o[5] = b[2] - a[2];
+        o[6] = c[0] - a[0]; o[7] = c[1] - a[1]; o[8] = c[2] - a[2];
+        memcpy(&o[9], &off, 4);
     }
-    return REF_LEAF | ((cnt < REF_COUNT_MAX ? cnt : REF_COUNT_MAX) << REF_SLOT_BITS) | (cnt ? start : 0u);
+    return REF_LEAF | ((is_long ? REF_COUNT_MAX : cnt) << REF_SLOT_BITS) | start;
 }
 
 /* Returns the reference of n (layout: rt_hip.h).  An interior node becomes the
@@ -503,6 +542,90 @@ static uint32_t flatten_rec(flat_ctx *fc, const kd_tree_node *n, uint32_t depth)
     return self << 2;
 }
 
+/* The record references among the eight words of a record: for each child of
+ * the top that is interior, the two words of that child's children, where they
+ * do not hold leaf descriptors. */
+static int record_children(const uint32_t *rec, int word[4])
+{
+    int n = 0;
+    for (int side = 0; side < 2; side++) {
+        if (rec[3] & (64u << side)) continue;
+        for (int j = 0; j < 2; j++)
+            if (!(rec[4 + 2 * side + j] & REF_LEAF)) word[n++] = 4 + 2 * side + j;
+    }
+    return n;
+}
+
+/* Re-orders the records (depth-first order as flatten_rec leaves them) so that
+ * a ray's way down the tree touches few 128-byte lines of the array, which is
+ * what a scattered fetch costs whether it uses 32 of the bytes or all: every
+ * line of four records holds connected pieces of the tree.  A piece is a
+ * head, then records picked one at a time as the largest subtree among the
+ * children of those already in it, until the line is full; the children left
+ * over head pieces of their own.  A whole subtree of at most three records
+ * goes into the slots an earlier line left free, if one has as many.  Lines
+ * are laid out breadth-first, the root's first.  Slots that stay free hold
+ * zeros and nothing refers to them.  Updates the references in
+ * the records and *root_ref; returns the new array and its record count. */
+static uint32_t *cluster_records(const uint32_t *nodes, uint32_t n, uint32_t *root_ref, uint32_t *num_out)
+{
+    uint32_t *size = (uint32_t *)malloc(sizeof(uint32_t) * n);
+    uint32_t *place = (uint32_t *)malloc(sizeof(uint32_t) * n);
+    uint32_t *queue = (uint32_t *)malloc(sizeof(uint32_t) * n);
+    int word[4];
+    for (uint32_t i = n; i-- > 0;) {            /* children follow their parent in depth-first order */
+        const uint32_t *rec = nodes + 8 * (size_t)i;
+        const int k = record_children(rec, word);
+        size[i] = 1;
+        for (int j = 0; j < k; j++) size[i] += size[rec[word[j]] >> 2];
+    }
+    uint32_t head = 0, tail = 0, lines = 0;
+    uint32_t *open[4] = {NULL, NULL, NULL, NULL}, nopen[4] = {0, 0, 0, 0};   /* first free slot of lines with 1..3 free */
+    for (int f = 1; f < 4; f++) open[f] = (uint32_t *)malloc(sizeof(uint32_t) * n);
+    queue[tail++] = *root_ref >> 2;
+    while (head < tail) {
+        const uint32_t first = queue[head++];
+        uint32_t frontier[16];
+        int nf = 0, filled = 0, room = 4;
+        uint32_t slot = 0;
+        /* a piece of at most three records fits whole into what another line left free */
+        for (int f = (int)size[first]; f < 4; f++)
+            if (nopen[f]) { slot = open[f][--nopen[f]]; room = f; break; }
+        if (room == 4) slot = 4u * lines++;
+        uint32_t member = first;
+        for (;;) {
+            place[member] = slot++;
+            const uint32_t *rec = nodes + 8 * (size_t)member;
+            const int k = record_children(rec, word);
+            for (int j = 0; j < k; j++) frontier[nf++] = rec[word[j]] >> 2;
+            if (++filled == room || nf == 0) break;
+            int best = 0;
+            for (int j = 1; j < nf; j++)
+                if (size[frontier[j]] > size[frontier[best]]) best = j;
+            member = frontier[best];
+            frontier[best] = frontier[--nf];
+        }
+        if (filled < room) open[room - filled][nopen[room - filled]++] = slot;
+        for (int j = 0; j < nf; j++) queue[tail++] = frontier[j];
+    }
+    for (int f = 1; f < 4; f++) free(open[f]);
+    if (4u * (uint64_t)lines >= (1u << 27)) {
+        fprintf(stderr, "ERROR: kd-tree too large for the flattened layout (%u lines of node records)\n", lines);
+        exit(1);
+    }
+    uint32_t *out = (uint32_t *)calloc((size_t)lines * 4u, sizeof(uint32_t) * 8);
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t *rec = out + 8 * (size_t)place[i];
+        memcpy(rec, nodes + 8 * (size_t)i, sizeof(uint32_t) * 8);
+        const int k = record_children(rec, word);
+        for (int j = 0; j < k; j++) rec[word[j]] = place[rec[word[j]] >> 2] << 2;
+    }
+    *root_ref = place[*root_ref >> 2] << 2;
+    *num_out = lines * 4u;
+    free(size); free(place); free(queue);
+    return out;
+}
+
 void kd_tree_flatten(kd_tree *tree)
 {
     kd_tree_flat *f = &tree->flat;
@@ -510,24 +633,28 @@ void kd_tree_flatten(kd_tree *tree)
     memset(f, 0, sizeof *f);
     if (!tree->root) return;
     /* also keeps both device arrays below 4 GiB: the kernels use 32-bit byte offsets */
-    if (tree->num_traversal_nodes >= (1u << 27) || tree->num_indices_total >= (1u << REF_SLOT_BITS)) {
-        fprintf(stderr, "ERROR: kd-tree too large for the flattened layout (%u interior nodes, %u leaf slots)\n",
-                tree->num_traversal_nodes, tree->num_indices_total);
+    if (tree->num_traversal_nodes >= (1u << 27)) {
+        fprintf(stderr, "ERROR: kd-tree too large for the flattened layout (%u interior nodes)\n",
+                tree->num_traversal_nodes);
         exit(1);
     }
     /* every record holds at least its top node, so the interior-node count bounds the record count */
-    f->num_leaf_slots = tree->num_indices_total;
     f->nodes = (uint32_t *)malloc(sizeof(uint32_t) * 8 * (size_t)(tree->num_traversal_nodes ? tree->num_traversal_nodes : 1));
-    f->leaf_tris = (float *)malloc(sizeof(float) * 12 * (size_t)(f->num_leaf_slots ? f->num_leaf_slots : 1));
     flat_ctx fc;
     fc.f = f;
     fc.verts = (const float (*)[4])tree->s->mesh_verts;
     fc.idx = (const int (*)[4])tree->s->mesh_indices;
-    fc.next_node = fc.next_slot = fc.depth_max = 0;
+    fc.next_node = fc.next_line = fc.cap_lines = fc.depth_max = fc.hole = fc.has_hole = 0;
     fc.plain_splits = 1;
     f->root_ref = flatten_rec(&fc, tree->root, 0);
     f->num_nodes = fc.next_node;
-    f->nodes = (uint32_t *)realloc(f->nodes, sizeof(uint32_t) * 8 * (size_t)(f->num_nodes ? f->num_nodes : 1));
+    f->num_leaf_lines = fc.next_line;
+    f->leaf_tris = (float *)realloc(f->leaf_tris, (size_t)(fc.next_line ? fc.next_line : 1) * LEAF_LINE_BYTES);
+    if (f->num_nodes) {
+        uint32_t *clustered = cluster_records(f->nodes, f->num_nodes, &f->root_ref, &f->num_nodes);
+        free(f->nodes);
+        f->nodes = clustered;
+    }
     f->max_depth = fc.depth_max;
     f->plain_splits = (uint32_t)fc.plain_splits;
     if (fc.depth_max >= RT_MAX_STACK) {        /* a ray pushes at most one entry per level */

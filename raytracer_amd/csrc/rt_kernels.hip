@@ -232,6 +232,15 @@ __device__ __forceinline__ void undefined_words(uint4 &x)
 {
     asm volatile("" : "=v"(x.x), "=v"(x.y), "=v"(x.z), "=v"(x.w));
 }
+__device__ __forceinline__ void undefined_words(uint2 &x)
+{
+    asm volatile("" : "=v"(x.x), "=v"(x.y));
+}
+template <class W4>
+__device__ __forceinline__ void undefined_words(W4 &x)
+{
+    asm volatile("" : "=v"(x.x), "=v"(x.y), "=v"(x.z), "=v"(x.w));
+}
 
 // The walk steps below are written for a wave whose lanes are in different
 // states: every lane runs the same straight instruction stream and `en` (or
@@ -408,10 +417,36 @@ __device__ __forceinline__ bool walk_leaf(const TravScene &P, Walk &w, f3 o, f3 
     return walk_leaf_step<LDS_DEPTH>(P, w, o, d, T0, T1, T2, pd, in_leaf, has, moved);
 }
 
+// A slot of leaf_tris (40 bytes, 8-byte aligned: rt_hip.h) as it is loaded, and its parts as the test takes them.
+struct __attribute__((aligned(8))) SlotWords4 { uint32_t x, y, z, w; };
+struct LeafSlot { SlotWords4 a, b; uint2 c; };
+
+__device__ __forceinline__ LeafSlot leaf_slot_load(const TravScene &P, const Walk &w)
+{
+    const char *p = (const char *)P.leaf_tris + (((w.ref & RT_REF_SLOT_MASK) << 6) + w.li * 40u);
+    LeafSlot t;
+    t.a = *(const SlotWords4 *)p;
+    t.b = *(const SlotWords4 *)(p + 16);
+    t.c = *(const uint2 *)(p + 32);
+    return t;
+}
+__device__ __forceinline__ float4 leaf_slot_v0(const LeafSlot &t)      // .w = the triangle's index offset
+{
+    return make_float4(__uint_as_float(t.a.x), __uint_as_float(t.a.y), __uint_as_float(t.a.z), __uint_as_float(t.c.y));
+}
+__device__ __forceinline__ float4 leaf_slot_e1(const LeafSlot &t)
+{
+    return make_float4(__uint_as_float(t.a.w), __uint_as_float(t.b.x), __uint_as_float(t.b.y), 0.f);
+}
+__device__ __forceinline__ float4 leaf_slot_e2(const LeafSlot &t)
+{
+    return make_float4(__uint_as_float(t.b.z), __uint_as_float(t.b.w), __uint_as_float(t.c.x), 0.f);
+}
+
 // walk_leaf with the triangle fetch: lanes that have a triangle left load it
-// (48 bytes), the others pay for no cache lookup.  The triangle count of the
-// leaf is settled at its first step: the descriptor's, or for a long leaf the
-// one stored with the first triangle.
+// (40 bytes), the others pay for no cache lookup.  The slot count of the leaf
+// is settled at its first step: the descriptor's triangle count, or for a
+// long leaf the one its header slot carries.
 template <int LDS_DEPTH>
 __device__ __forceinline__ bool walk_leaf_load(const TravScene &P, Walk &w, f3 o, f3 d, uint2 *__restrict__ col,
                                                uint2 *__restrict__ spill, bool in_leaf)
@@ -420,16 +455,11 @@ __device__ __forceinline__ bool walk_leaf_load(const TravScene &P, Walk &w, f3 o
     const uint32_t count = RT_REF_COUNT(w.ref);
     w.lc = first ? count : w.lc;
     const bool has = in_leaf & (w.li < w.lc);
-    uint4 t0, t1, t2;
-    undefined_words(t0); undefined_words(t1); undefined_words(t2);
-    if (has) {
-        const uint4 *tp = (const uint4 *)((const char *)P.leaf_tris + ((w.ref & RT_REF_SLOT_MASK) + w.li) * 48u);
-        t0 = tp[0]; t1 = tp[1]; t2 = tp[2];
-    }
-    w.lc = (first & (count == 31u)) ? t1.w : w.lc;
-    const float4 T0 = make_float4(__uint_as_float(t0.x), __uint_as_float(t0.y), __uint_as_float(t0.z), __uint_as_float(t0.w));
-    const float4 T1 = make_float4(__uint_as_float(t1.x), __uint_as_float(t1.y), __uint_as_float(t1.z), __uint_as_float(t1.w));
-    const float4 T2 = make_float4(__uint_as_float(t2.x), __uint_as_float(t2.y), __uint_as_float(t2.z), __uint_as_float(t2.w));
+    LeafSlot t;
+    undefined_words(t.a); undefined_words(t.b); undefined_words(t.c);
+    if (has) t = leaf_slot_load(P, w);
+    w.lc = (first & (count == 31u)) ? t.c.y : w.lc;
+    const float4 T0 = leaf_slot_v0(t), T1 = leaf_slot_e1(t), T2 = leaf_slot_e2(t);
     return walk_leaf<LDS_DEPTH>(P, w, o, d, T0, T1, T2, col, spill, in_leaf, has);
 }
 
@@ -454,30 +484,26 @@ __device__ __forceinline__ bool walk_trip_fused(const TravScene &P, Walk &w, f3 
     const uint32_t count = RT_REF_COUNT(w.ref);
     w.lc = first ? count : w.lc;
     const bool has = in_leaf & (w.li < w.lc);
-    // a long leaf keeps its count with its first triangle: not known before that arrives, and never used up by it
+    // a long leaf keeps its count in its header slot: not known before that arrives, and never used up by it
     const bool leaving = in_leaf & !(first & (count == 31u)) & (w.li + 1u >= w.lc);
     const PopData pd = walk_peek<LDS_DEPTH>(P, w, col, spill, leaving & (w.sp != 0u));
     const bool ahead = leaving & !(pd.e.x & RT_REF_LEAF);          // continues at an interior node: fetch it now
 
-    uint4 a, r, t0, t1, t2;
-    undefined_words(a); undefined_words(r); undefined_words(t0); undefined_words(t1); undefined_words(t2);
+    uint4 a, r;
+    LeafSlot t;
+    undefined_words(a); undefined_words(r); undefined_words(t.a); undefined_words(t.b); undefined_words(t.c);
     if (in_node | ahead) {
         const uint32_t top = (in_node ? w.ref : pd.e.x) & ~3u;
         const uint4 *rec = (const uint4 *)((const char *)P.nodes + (top << 3));
         a = rec[0]; r = rec[1];
     }
-    if (has) {
-        const uint4 *tp = (const uint4 *)((const char *)P.leaf_tris + ((w.ref & RT_REF_SLOT_MASK) + w.li) * 48u);
-        t0 = tp[0]; t1 = tp[1]; t2 = tp[2];
-    }
+    if (has) t = leaf_slot_load(P, w);
     // all five loads leave here, together, before anything waits for one of them
     asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(r.x), "+v"(r.y), "+v"(r.z), "+v"(r.w));
-    asm volatile("" : "+v"(t0.x), "+v"(t0.y), "+v"(t0.z), "+v"(t0.w), "+v"(t1.x), "+v"(t1.y), "+v"(t1.z), "+v"(t1.w),
-                      "+v"(t2.x), "+v"(t2.y), "+v"(t2.z));
-    w.lc = (first & (count == 31u)) ? t1.w : w.lc;
-    const float4 T0 = make_float4(__uint_as_float(t0.x), __uint_as_float(t0.y), __uint_as_float(t0.z), __uint_as_float(t0.w));
-    const float4 T1 = make_float4(__uint_as_float(t1.x), __uint_as_float(t1.y), __uint_as_float(t1.z), __uint_as_float(t1.w));
-    const float4 T2 = make_float4(__uint_as_float(t2.x), __uint_as_float(t2.y), __uint_as_float(t2.z), __uint_as_float(t2.w));
+    asm volatile("" : "+v"(t.a.x), "+v"(t.a.y), "+v"(t.a.z), "+v"(t.a.w), "+v"(t.b.x), "+v"(t.b.y), "+v"(t.b.z), "+v"(t.b.w),
+                      "+v"(t.c.x), "+v"(t.c.y));
+    w.lc = (first & (count == 31u)) ? t.c.y : w.lc;
+    const float4 T0 = leaf_slot_v0(t), T1 = leaf_slot_e1(t), T2 = leaf_slot_e2(t);
     bool moved;
     const bool fin = walk_leaf_step<LDS_DEPTH>(P, w, o, d, T0, T1, T2, pd, in_leaf, has, moved);
     walk_record_steps<LDS_DEPTH>(w, o, d, rd, plain, a, r, col, spill, in_node | (moved & ahead));
@@ -1454,6 +1480,10 @@ void launch_spath_run(rt_device *dev, const TravScene &P, const SpathDev &B, uin
     case 22: launch_run_variant<12, 16, 64, 0, 0, 6>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
     case 23: launch_run_variant<10, 16, 64, 0, 0, 8>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
     case 24: launch_run_variant<16, 16, 64, 0, 0, 5>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
+    case 25: launch_run_variant<16, 16, 64, 2, 2, 4>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
+    case 26: launch_run_variant<16, 16, 64, 2, 2, 3>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
+    case 27: launch_run_variant<16, 16, 64, 1, 1, 4>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
+    case 28: launch_run_variant<16, 16, 64, 3, 3, 4>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
     default: launch_run_variant<10, 16, 64, 1, 1, 7>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
     }
 }
@@ -1539,7 +1569,7 @@ int rt_k_kd_intersect_noalloc(rt_device *dev, const rt_kd_view *kd, rt_mem ray_o
                         "(the 32-bit work counter is claimed in chunks past the end)\n", n, (unsigned)RT_NOALLOC_MAX_RAYS);
         return 1;
     }
-    if (!kd || !kd->nodes || !kd->leaf_tris || kd->num_leaf_slots == 0 || kd->max_depth >= RT_MAX_STACK || !ray_o ||
+    if (!kd || !kd->nodes || !kd->leaf_tris || kd->num_leaf_lines == 0 || kd->max_depth >= RT_MAX_STACK || !ray_o ||
         !ray_d || !hits || !dev->static_counters) {
         fprintf(stderr, "ERROR: rt_k_kd_intersect_noalloc: no flattened kd-tree, or a null ray / hit buffer\n");
         return 2;

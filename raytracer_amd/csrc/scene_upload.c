@@ -114,12 +114,12 @@ void scene_resource_push(raytracer_context *rctx)
         kdt->cl_kd_tree_buffer = upload_array(rctx, kdt->flat.nodes, sizeof(uint32_t) * 8 * (size_t)kdt->flat.num_nodes);
         kdt->view.nodes = kdt->cl_kd_tree_buffer;
         /* the kernels may read slot 0 / node 0 as a harmless dummy: keep both allocated */
-        kdt->view.leaf_tris = rt_mem_alloc(dev, sizeof(float) * 12 * ((size_t)kdt->flat.num_leaf_slots + 1));
-        rt_mem_zero(dev, kdt->view.leaf_tris, sizeof(float) * 12 * ((size_t)kdt->flat.num_leaf_slots + 1));
-        if (kdt->flat.num_leaf_slots)
-            rt_mem_upload(dev, kdt->view.leaf_tris, kdt->flat.leaf_tris, sizeof(float) * 12 * (size_t)kdt->flat.num_leaf_slots);
+        kdt->view.leaf_tris = rt_mem_alloc(dev, 64u * ((size_t)kdt->flat.num_leaf_lines + 1));
+        rt_mem_zero(dev, kdt->view.leaf_tris, 64u * ((size_t)kdt->flat.num_leaf_lines + 1));
+        if (kdt->flat.num_leaf_lines)
+            rt_mem_upload(dev, kdt->view.leaf_tris, kdt->flat.leaf_tris, 64u * (size_t)kdt->flat.num_leaf_lines);
         kdt->view.num_nodes = kdt->flat.num_nodes;
-        kdt->view.num_leaf_slots = kdt->flat.num_leaf_slots;
+        kdt->view.num_leaf_lines = kdt->flat.num_leaf_lines;
         kdt->view.num_tris = num_tris;
         kdt->view.root_ref = kdt->flat.root_ref;
         kdt->view.max_depth = kdt->flat.max_depth;

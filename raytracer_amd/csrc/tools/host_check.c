@@ -24,7 +24,7 @@ int main(int argc, char **argv)
         kd_tree_generate_serialized(t);
         kd_tree_flatten(t);
         printf("%s: %u nodes, blob %u bytes, %u records, %u slots\n", argv[i], t->num_nodes_total, t->buffer_size,
-               t->flat.num_nodes, t->flat.num_leaf_slots);
+               t->flat.num_nodes, t->flat.num_leaf_lines);
         kd_tree_free(t);
         scene_free(s);
     }

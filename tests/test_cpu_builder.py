@@ -98,16 +98,22 @@ def test_product_builder_matches_oracle(rt, orc, name, threads):
 
 def _decode_flat(hk):
     """Depth-first walk of the flattened tree: (leaves as index-offset tuples, interior nodes as (axis, split bits))."""
-    leaves, interior = [], []
+    leaves, interior, used = [], [], set()
+    words = hk.leaf_tris.view(np.uint32).reshape(-1)
 
     def walk(ref):
         if ref & 0x80000000:
-            cnt, slot = (ref >> 26) & 31, ref & 0x03FFFFFF
-            if cnt == 31:
-                cnt = int(hk.leaf_tris[slot, 7].view(np.uint32))
-            leaves.append(tuple(int(hk.leaf_tris[slot + i, 3].view(np.uint32)) for i in range(cnt)))
+            cnt, line = (ref >> 26) & 31, ref & 0x03FFFFFF
+            slots = words[16 * line:].reshape(-1)                   # 10 words per slot from the leaf's first line
+            first = 0
+            if cnt == 31:                                           # header slot: zero-extent triangle + slot count
+                assert not slots[:9].any()
+                cnt, first = int(slots[9]), 1
+            assert cnt == 0 or line + (40 * cnt + 63) // 64 <= hk.leaf_tris.shape[0]
+            leaves.append(tuple(int(slots[10 * i + 9]) for i in range(first, cnt)))
             return
         rec, pos = hk.nodes[ref >> 2], ref & 3
+        used.add(ref >> 2)
         packed = int(rec[3])
         interior.append(((packed >> (2 * pos)) & 3, int(rec[pos])))
         if pos == 0:       # top of a record: its children are positions 1 / 2 of the same record, or leaves
@@ -120,7 +126,17 @@ def _decode_flat(hk):
     import sys
     sys.setrecursionlimit(10000)
     walk(hk.root_ref)
-    return leaves, interior
+    return leaves, interior, used
+
+
+def _leaf_refs(hk, used):
+    for i in used:
+        rec = hk.nodes[i]
+        for side in (0, 1):
+            words = (4 + 2 * side,) if int(rec[3]) & (64 << side) else (4 + 2 * side, 5 + 2 * side)
+            for wd in words:
+                if int(rec[wd]) & 0x80000000:
+                    yield int(rec[wd])
 
 
 def _decode_blob(blob):
@@ -145,17 +161,38 @@ def test_flattened_tree_has_the_same_leaves_in_the_same_order(rt, orc, name):
     sc = _scenes(rt)[name]
     hk = rt.HostKdTree(sc)
     kt = orc.KdTree(sc.verts4, sc.idx4)
-    flat_leaves, flat_interior = _decode_flat(hk)
+    flat_leaves, flat_interior, used = _decode_flat(hk)
     blob_leaves, blob_interior = _decode_blob(kt.blob[:kt.blob_used])
     assert flat_leaves == blob_leaves
     assert flat_interior == blob_interior and len(flat_interior) == hk.counts["traversal"]
-    assert hk.nodes.shape[0] < hk.counts["traversal"]          # two levels per record
+    assert len(used) < hk.counts["traversal"]                  # two levels per record
+    # lines of four records holding connected pieces of the tree: most records are referred to from a record of
+    # their own line; slots nothing refers to hold zeros
+    assert hk.nodes.shape[0] % 4 == 0 and len(used) > 0.8 * hk.nodes.shape[0]
+    free = np.setdiff1d(np.arange(hk.nodes.shape[0]), sorted(used))
+    assert not hk.nodes[free].any()
+    parents = {}
+    for i in used:
+        rec = hk.nodes[i]
+        for side in (0, 1):
+            if not int(rec[3]) & (64 << side):
+                for wd in (4 + 2 * side, 5 + 2 * side):
+                    if not int(rec[wd]) & 0x80000000:
+                        parents[int(rec[wd]) >> 2] = i
+    together = sum(parents[i] // 4 == i // 4 for i in used if i in parents)
+    assert together > 0.4 * len(used)               # three of every four at best
+    # a leaf of two lines (2 or 3 triangles) lies in one aligned pair of lines
+    for ref in _leaf_refs(hk, used):
+        cnt, line = (ref >> 26) & 31, ref & 0x03FFFFFF
+        if cnt in (2, 3):
+            assert line % 2 == 0
     # precomputed edges are exactly v1-v0, v2-v0
-    off = int(hk.leaf_tris[0, 3].view(np.uint32))
+    first = hk.leaf_tris.reshape(-1)[:10]
+    off = int(first[9:10].view(np.uint32)[0])
     a, b, c = (sc.verts4[sc.idx4[off + i, 0], :3] for i in range(3))
-    assert np.array_equal(hk.leaf_tris[0, 0:3], a)
-    assert np.array_equal(hk.leaf_tris[0, 4:7], b - a)
-    assert np.array_equal(hk.leaf_tris[0, 8:11], c - a)
+    assert np.array_equal(first[0:3], a)
+    assert np.array_equal(first[3:6], b - a)
+    assert np.array_equal(first[6:9], c - a)
 
 
 def test_single_leaf_tree_and_empty_scene(rt, orc):
