@@ -232,6 +232,27 @@ def mixed_scene(level: int = 2) -> SceneArrays:
     return _assemble([(pos, nrm, f, f, 4)], _materials(_PATH_MATERIALS), base.spheres, base.planes)
 
 
+def bundle_scene(copies=(45, 33)) -> SceneArrays:
+    """Stacks of coincident triangles in the room of icosphere_scene: the builder cannot separate triangles that
+    cover one another exactly, so each stack ends up in one leaf, longer than a leaf descriptor's count field holds
+    (rt_hip.h: 31 = "the leaf begins with a header slot").  Of a stack a ray reports the first triangle."""
+    shapes = [((-2.5, -2.0, -7.0), (0.5, -1.5, -6.0), (-1.0, 2.0, -8.0)),
+              ((1.2, -2.5, -5.0), (3.6, -1.0, -6.5), (2.4, 1.5, -5.5)),
+              ((-1.0, -3.0, -4.0), (1.0, -3.2, -4.5), (0.0, -1.0, -4.2))]
+    parts = []
+    for k, c in enumerate(copies):
+        tri = np.array(shapes[k % len(shapes)], np.float32)
+        g = np.cross(tri[1] - tri[0], tri[2] - tri[0])
+        if g[2] < 0:                                    # face the camera (which looks down -z)
+            tri = tri[::-1].copy()
+            g = -g
+        v = np.tile(tri, (c, 1))
+        n = (g / np.linalg.norm(g))[None, :].astype(np.float32)
+        fv = np.arange(3 * c, dtype=np.int64).reshape(-1, 3)
+        parts.append((v, n, fv, np.zeros((c, 3), np.int64), 3 if k % 2 == 0 else 0))
+    return _assemble(parts + _room_parts(), _materials(_PATH_MATERIALS))
+
+
 def scene_from_npz(path: str) -> SceneArrays:
     """Scene arrays stored by the fixture scripts under tests/golden (np.savez of a loaded scene)."""
     z = np.load(path)

@@ -13,10 +13,10 @@ GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 def _scenes(rt):
     s = rt.scenes
     return {"ico2": s.icosphere_scene(2), "ico4": s.icosphere_scene(4), "soup2k": s.soup_scene(2000),
-            "mixed": s.mixed_scene(2)}
+            "mixed": s.mixed_scene(2), "bundles": s.bundle_scene()}
 
 
-@pytest.mark.parametrize("name", ["ico2", "ico4", "soup2k", "mixed"])
+@pytest.mark.parametrize("name", ["ico2", "ico4", "soup2k", "mixed", "bundles"])
 def test_oracle_builder_matches_reference_builder(rt, orc, name):
     if orc.ref_lib() is None:
         pytest.skip("oracle/_ref not built (no reference checkout here)")
@@ -84,7 +84,7 @@ def test_reference_scenes_through_loader_and_all_three_builders(rt, orc, case):
     assert (hk.blob == kt.blob[:kt.blob_size]).all()
 
 
-@pytest.mark.parametrize("name", ["ico2", "ico4", "soup2k", "mixed"])
+@pytest.mark.parametrize("name", ["ico2", "ico4", "soup2k", "mixed", "bundles"])
 @pytest.mark.parametrize("threads", [1, 4])
 def test_product_builder_matches_oracle(rt, orc, name, threads):
     sc = _scenes(rt)[name]
@@ -154,6 +154,24 @@ def _decode_blob(blob):
         else:
             break
     return leaves, interior
+
+
+def test_leaves_longer_than_the_descriptor_count(rt, orc):
+    """Stacks of 45 and 33 coincident triangles: one leaf each, with a header slot (a triangle of zero extent whose
+    last word is the slot count) in front of the triangles."""
+    sc = _scenes(rt)["bundles"]
+    hk = rt.HostKdTree(sc)
+    kt = orc.KdTree(sc.verts4, sc.idx4)
+    flat_leaves, flat_interior, used = _decode_flat(hk)
+    blob_leaves, blob_interior = _decode_blob(kt.blob[:kt.blob_used])
+    assert flat_leaves == blob_leaves and flat_interior == blob_interior
+    assert sorted(len(l) for l in flat_leaves if len(l) >= 31) == [33, 45]
+    long_refs = [r for r in _leaf_refs(hk, used) if (r >> 26) & 31 == 31]
+    assert len(long_refs) == 2
+    words = hk.leaf_tris.view(np.uint32).reshape(-1)
+    for r in long_refs:
+        line = r & 0x03FFFFFF
+        assert not words[16 * line:16 * line + 9].any() and int(words[16 * line + 9]) in (46, 34)
 
 
 @pytest.mark.parametrize("name", ["ico4", "soup2k"])

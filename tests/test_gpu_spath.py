@@ -237,6 +237,31 @@ def test_deep_stack_scene_bit_exact(rt, orc, schedule):
     assert stats["max_stack"] > 12, stats
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("schedule", [0, 1, 2])
+def test_long_leaves_bit_exact(rt, orc, schedule):
+    """Leaves of 45 and 33 triangles (stacks of coincident ones): more than a leaf descriptor's count field holds, so
+    the walk reads the count from the leaf's header slot; of a stack the first triangle in stored order is reported,
+    as by the reference's strict t < t_hit."""
+    sc = rt.scenes.bundle_scene()
+    tree = orc.KdTree(sc.verts4, sc.idx4)
+    w, h, iters, seed = 96, 64, 6, 5
+    r = rt.Renderer(sc, w, h).build()
+    r.init_spath(seed=seed, resolve_interval=0, schedule=schedule)
+    r.spath_prepass(num_iterations=iters)
+    r.spath_render(iters)
+    g = r.spath_state()
+    r.close()
+    st = oracle_spath_run(orc, sc, tree, w, h, seed, iters)
+    hits_equal(g["source_results"], st.source_results, "primary hits")
+    hits_equal(g["results"], st.results, "bounce hits")
+    assert_bits_equal(g["out_tex"], st.out_tex, "out_tex")
+    assert_bits_equal(g["rays"], st.rays, "rays")
+    first_of_stack = np.isin(st.source_results["tri"], [0, 3 * 45]) & (st.source_results["t"] != 0)
+    in_stack = (st.source_results["tri"] < 3 * (45 + 33)) & (st.source_results["t"] != 0)
+    assert first_of_stack.sum() > 100 and (first_of_stack == in_stack).all()
+
+
 def test_scene_file_to_pixels(rt, orc, tmp_path):
     """The whole drop-in chain: .rsc + OBJ files -> load_scene_json_url -> build -> SPATH, against the oracle
     fed with the arrays the loader produced."""
