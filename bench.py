@@ -315,10 +315,7 @@ def main():
         wire = frame if backend == "nccl" else torch.empty(n_local, dtype=torch.int32)    # gloo moves host tensors
         gathered = [torch.empty_like(wire) for _ in range(world)] if rank == 0 else None
 
-    sync_all()
-    t0 = time.perf_counter()
-    r.spath_render(args.steps)
-    if torch is not None:
+    def gather_frame():
         # resolve this strip, hand it to torch and gather the frame on rank 0 (RCCL)
         r.L.rt_k_resolve_avg(r.dev, r.rctx.contents.cl_output_buffer, r.spath.contents.cl_path_output_buffer, n_local)
         r.L.rt_mem_copy(r.dev, frame.data_ptr(), r.rctx.contents.cl_output_buffer, n_local * 4)
@@ -326,6 +323,21 @@ def main():
         if wire is not frame:
             wire.copy_(frame)
         dist.gather(wire, gathered, dst=0)
+
+    if torch is not None:
+        gather_frame()      # part of the warm-up: the first gather sets up the point-to-point connections it uses
+    sync_all()
+    t0 = time.perf_counter()
+    r.spath_render(args.steps)
+    if os.environ.get("RT_BENCH_TRACE") and torch is not None:      # where the timed region's tail goes
+        r.sync(); ta = time.perf_counter()
+        gather_frame(); tb = time.perf_counter()
+        r.sync(); torch.cuda.synchronize(); tc = time.perf_counter()
+        dist.barrier(); td = time.perf_counter()
+        log(f"[bench trace] rank {rank}: render {1e3 * (ta - t0):.3f} ms, resolve+gather {1e3 * (tb - ta):.3f}, "
+            f"sync {1e3 * (tc - tb):.3f}, barrier {1e3 * (td - tc):.3f}")
+    elif torch is not None:
+        gather_frame()
     sync_all()
     dt = time.perf_counter() - t0
     if torch is not None:
