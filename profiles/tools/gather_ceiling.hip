@@ -3,6 +3,7 @@
 //   0  16 bytes of a random 64-byte line                       3  all 128 bytes of a random 128-byte line
 //   1  48 bytes (3 loads) of a random 64-byte line              4  32 bytes of a random 32-byte record
 //   2  both 64-byte halves (16 bytes each) of a random 128-byte line
+//   5 / 6 / 7  16 bytes of each 64-byte line of a random aligned block of 256 / 512 / 1024 bytes
 // Prints records/s and the bytes/s that are whole 64-byte lines touched.
 // build: hipcc -O3 --offload-arch=gfx950 -o gather_ceiling gather_ceiling.hip
 #include <hip/hip_runtime.h>
@@ -37,10 +38,20 @@ __global__ __launch_bounds__(256) void k_gather(const uint4 *__restrict__ buf, u
                 for (int k = 0; k < 8; k++) v[j][k] = buf[(size_t)r * 8 + k];
             }
             if (PATTERN == 4) { v[j][0] = buf[(size_t)r * 2]; v[j][1] = buf[(size_t)r * 2 + 1]; }
+            if (PATTERN >= 5) {
+                constexpr int LINES = PATTERN == 5 ? 4 : PATTERN == 6 ? 8 : 16;
+                uint4 acc4 = buf[(size_t)r * LINES * 4];
+#pragma unroll
+                for (int k = 1; k < LINES; k++) {
+                    const uint4 x = buf[((size_t)r * LINES + k) * 4];
+                    acc4.x ^= x.x; acc4.w += x.w;
+                }
+                v[j][0] = acc4;
+            }
         }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const int nk = PATTERN == 0 ? 1 : PATTERN == 1 ? 3 : PATTERN == 3 ? 8 : 2;
+            const int nk = (PATTERN == 0 || PATTERN >= 5) ? 1 : PATTERN == 1 ? 3 : PATTERN == 3 ? 8 : 2;
 #pragma unroll
             for (int k = 0; k < nk; k++) acc += v[j][k].x ^ v[j][k].w;
         }
@@ -60,9 +71,9 @@ int main(int argc, char **argv)
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, 0));
     const int blocks = prop.multiProcessorCount * waves_per_simd;       // 256 threads = 4 waves = one per SIMD
-    const size_t rec_bytes[5] = {64, 64, 128, 128, 32};
-    const size_t line_bytes[5] = {64, 64, 128, 128, 32};
-    for (int p = 0; p < 5; p++) {
+    const size_t rec_bytes[8] = {64, 64, 128, 128, 32, 256, 512, 1024};
+    const size_t line_bytes[8] = {64, 64, 128, 128, 32, 256, 512, 1024};
+    for (int p = 0; p < 8; p++) {
         const uint32_t records = (uint32_t)(footprint / rec_bytes[p]);
         hipEvent_t a, b;
         CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
@@ -74,6 +85,9 @@ int main(int argc, char **argv)
             case 2: k_gather<2><<<blocks, 256>>>(buf, records, per_lane, sink); break;
             case 3: k_gather<3><<<blocks, 256>>>(buf, records, per_lane, sink); break;
             case 4: k_gather<4><<<blocks, 256>>>(buf, records, per_lane, sink); break;
+            case 5: k_gather<5><<<blocks, 256>>>(buf, records, per_lane, sink); break;
+            case 6: k_gather<6><<<blocks, 256>>>(buf, records, per_lane, sink); break;
+            case 7: k_gather<7><<<blocks, 256>>>(buf, records, per_lane, sink); break;
             }
             CHECK(hipEventRecord(b, 0));
             CHECK(hipEventSynchronize(b));
