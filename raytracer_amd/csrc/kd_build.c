@@ -438,6 +438,12 @@ void kd_tree_generate_serialized(kd_tree *tree)
 }
 
 /* ---- flattening ---------------------------------------------------------- */
+static void *must(void *p)           /* the arrays of a 10 M-triangle tree are gigabytes: say so when they cannot be had */
+{
+    if (!p) { fprintf(stderr, "ERROR: out of memory while flattening the kd-tree\n"); exit(1); }
+    return p;
+}
+
 #define REF_LEAF        0x80000000u
 #define REF_SLOT_BITS   26
 #define REF_COUNT_MAX   31u
@@ -473,7 +479,7 @@ static uint32_t flatten_leaf(flat_ctx *fc, const kd_tree_node *n)
     }
     if (fc->next_line + lines + 1u > fc->cap_lines) {
         while (fc->next_line + lines + 1u > fc->cap_lines) fc->cap_lines = fc->cap_lines ? fc->cap_lines * 2u : 1024u;
-        fc->f->leaf_tris = (float *)realloc(fc->f->leaf_tris, (size_t)fc->cap_lines * LEAF_LINE_BYTES);
+        fc->f->leaf_tris = (float *)must(realloc(fc->f->leaf_tris, (size_t)fc->cap_lines * LEAF_LINE_BYTES));
     }
     /* The memory system fetches 128 bytes for the price of 64: a leaf of an even number of lines starts on an
        even line, so that it lies in lines / 2 such pairs and not one more. */
@@ -569,9 +575,9 @@ static int record_children(const uint32_t *rec, int word[4])
  * the records and *root_ref; returns the new array and its record count. */
 static uint32_t *cluster_records(const uint32_t *nodes, uint32_t n, uint32_t *root_ref, uint32_t *num_out)
 {
-    uint32_t *size = (uint32_t *)malloc(sizeof(uint32_t) * n);
-    uint32_t *place = (uint32_t *)malloc(sizeof(uint32_t) * n);
-    uint32_t *queue = (uint32_t *)malloc(sizeof(uint32_t) * n);
+    uint32_t *size = (uint32_t *)must(malloc(sizeof(uint32_t) * n));
+    uint32_t *place = (uint32_t *)must(malloc(sizeof(uint32_t) * n));
+    uint32_t *queue = (uint32_t *)must(malloc(sizeof(uint32_t) * n));
     int word[4];
     for (uint32_t i = n; i-- > 0;) {            /* children follow their parent in depth-first order */
         const uint32_t *rec = nodes + 8 * (size_t)i;
@@ -581,7 +587,7 @@ static uint32_t *cluster_records(const uint32_t *nodes, uint32_t n, uint32_t *ro
     }
     uint32_t head = 0, tail = 0, lines = 0;
     uint32_t *open[4] = {NULL, NULL, NULL, NULL}, nopen[4] = {0, 0, 0, 0};   /* first free slot of lines with 1..3 free */
-    for (int f = 1; f < 4; f++) open[f] = (uint32_t *)malloc(sizeof(uint32_t) * n);
+    for (int f = 1; f < 4; f++) open[f] = (uint32_t *)must(malloc(sizeof(uint32_t) * n));
     queue[tail++] = *root_ref >> 2;
     while (head < tail) {
         const uint32_t first = queue[head++];
@@ -613,7 +619,7 @@ static uint32_t *cluster_records(const uint32_t *nodes, uint32_t n, uint32_t *ro
         fprintf(stderr, "ERROR: kd-tree too large for the flattened layout (%u lines of node records)\n", lines);
         exit(1);
     }
-    uint32_t *out = (uint32_t *)calloc((size_t)lines * 4u, sizeof(uint32_t) * 8);
+    uint32_t *out = (uint32_t *)must(calloc((size_t)lines * 4u, sizeof(uint32_t) * 8));
     for (uint32_t i = 0; i < n; i++) {
         uint32_t *rec = out + 8 * (size_t)place[i];
         memcpy(rec, nodes + 8 * (size_t)i, sizeof(uint32_t) * 8);
@@ -639,7 +645,7 @@ void kd_tree_flatten(kd_tree *tree)
         exit(1);
     }
     /* every record holds at least its top node, so the interior-node count bounds the record count */
-    f->nodes = (uint32_t *)malloc(sizeof(uint32_t) * 8 * (size_t)(tree->num_traversal_nodes ? tree->num_traversal_nodes : 1));
+    f->nodes = (uint32_t *)must(malloc(sizeof(uint32_t) * 8 * (size_t)(tree->num_traversal_nodes ? tree->num_traversal_nodes : 1)));
     flat_ctx fc;
     fc.f = f;
     fc.verts = (const float (*)[4])tree->s->mesh_verts;
@@ -649,7 +655,7 @@ void kd_tree_flatten(kd_tree *tree)
     f->root_ref = flatten_rec(&fc, tree->root, 0);
     f->num_nodes = fc.next_node;
     f->num_leaf_lines = fc.next_line;
-    f->leaf_tris = (float *)realloc(f->leaf_tris, (size_t)(fc.next_line ? fc.next_line : 1) * LEAF_LINE_BYTES);
+    f->leaf_tris = (float *)must(realloc(f->leaf_tris, (size_t)(fc.next_line ? fc.next_line : 1) * LEAF_LINE_BYTES));
     if (f->num_nodes) {
         uint32_t *clustered = cluster_records(f->nodes, f->num_nodes, &f->root_ref, &f->num_nodes);
         free(f->nodes);
