@@ -59,6 +59,22 @@ __global__ __launch_bounds__(256) void k_gather(const uint4 *__restrict__ buf, u
     if (acc == 0x12345678u) sink[0] = acc;
 }
 
+// The streaming ceiling beside it: every lane reads (or copies) consecutive 16-byte words, grid-stride.
+__global__ __launch_bounds__(256) void k_stream_read(const uint4 *__restrict__ buf, size_t words, uint32_t *__restrict__ sink)
+{
+    uint32_t acc = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x) {
+        const uint4 v = buf[i];
+        acc += v.x ^ v.w;
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+__global__ __launch_bounds__(256) void k_stream_copy(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t words)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x)
+        dst[i] = src[i];
+}
+
 int main(int argc, char **argv)
 {
     const size_t footprint = (argc > 1 ? (size_t)atof(argv[1]) : 1536) << 20;      // MiB
@@ -97,6 +113,29 @@ int main(int argc, char **argv)
         const double n = (double)blocks * 256 * per_lane;
         printf("pattern %d  footprint %zu MiB  waves/SIMD %d: %.1f G records/s, %.2f TB/s of %zu-byte records, %.3f ms\n", p,
                footprint >> 20, waves_per_simd, n / ms / 1e6, n * line_bytes[p] / ms / 1e9, line_bytes[p], ms);
+    }
+    {
+        const size_t words = footprint / 16;
+        hipEvent_t a, b;
+        CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+        float ms;
+        for (int rep = 0; rep < 3; rep++) {
+            CHECK(hipEventRecord(a, 0));
+            k_stream_read<<<prop.multiProcessorCount * 8, 256>>>(buf, words, sink);
+            CHECK(hipEventRecord(b, 0));
+            CHECK(hipEventSynchronize(b));
+        }
+        CHECK(hipEventElapsedTime(&ms, a, b));
+        printf("stream read  footprint %zu MiB: %.2f TB/s, %.3f ms\n", footprint >> 20, footprint / ms / 1e9, ms);
+        for (int rep = 0; rep < 3; rep++) {
+            CHECK(hipEventRecord(a, 0));
+            k_stream_copy<<<prop.multiProcessorCount * 8, 256>>>(buf, buf + words / 2, words / 2);
+            CHECK(hipEventRecord(b, 0));
+            CHECK(hipEventSynchronize(b));
+        }
+        CHECK(hipEventElapsedTime(&ms, a, b));
+        printf("stream copy  %zu MiB -> %zu MiB: %.2f TB/s read + written, %.3f ms\n", footprint >> 21, footprint >> 21,
+               footprint / ms / 1e9, ms);
     }
     return 0;
 }
