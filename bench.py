@@ -88,6 +88,55 @@ def host_cpu():
     return share, f"{model}; nproc {nproc}, affinity {affinity}, OMP_NUM_THREADS {env or 'unset'}"
 
 
+def oracle_tree(sc, r):
+    """The oracle's view of the serialised tree the library produced (the reference's wire format)."""
+    import oracle
+    kdt = r.kdt
+    blob = np.ctypeslib.as_array(kdt.buffer, shape=(int(kdt.buffer_size),))
+    return oracle.KdTree.from_blob(blob, sc.verts4, sc.idx4, kdt.bounds.min[:3], kdt.bounds.max[:3])
+
+
+def parity_gates(sc, r, width, full_height, n_local, frame_row0, rows, iterations, threads):
+    """The gates a number is reported with, checked on the state the device holds after the warm-up iterations
+    against the oracle (CPU restatement): (1) the first hit of EVERY primary ray of this rank's pixels -- triangle
+    index and the bits of t, u, v; (2) the accumulated radiance of `rows` frame rows from `frame_row0` (this rank's
+    first pixels when they are a band, the middle of the picture otherwise) after the same `iterations` iterations
+    with the same RNG streams.  Returns the `parity` object of the bench line."""
+    import oracle
+    from raytracer_amd.scenes import splitmix32
+    tree = oracle_tree(sc, r)
+    b = r.spath_buffers()
+    oo = r.download(b.origin_o, np.float32, 4 * n_local).reshape(n_local, 4)
+    od = r.download(b.origin_d, np.float32, 4 * n_local).reshape(n_local, 4)
+    got = r.download(b.source_hits, np.uint32, 4 * n_local).reshape(n_local, 4)
+    want = tree.intersect(np.ascontiguousarray(np.concatenate([oo, od], axis=1)), nthreads=threads)
+    id_bad = int((got[:, 0] != want["tri"]).sum())
+    tuv_bad = int(((got[:, 1] != want["t"].view(np.uint32)) | (got[:, 2] != want["u"].view(np.uint32))
+                   | (got[:, 3] != want["v"].view(np.uint32))).sum())
+    # radiance of a few rows
+    local0 = frame_row0 if n_local == width * full_height else 0          # a band starts at the rank's first pixel
+    st = oracle.SpathState(sc, tree, width, rows, frame_row0, full_height)
+    st.nthreads = threads
+    first = frame_row0 * width
+    rb = splitmix32(1, np.arange(first, first + width * rows, dtype=np.uint64))
+    rv = splitmix32(2, np.arange(iterations + 1, dtype=np.uint64))
+    st.prepass(rb, int(rv[0]))
+    for k in range(iterations):
+        st.iterate(int(rv[k + 1]))
+    base = b.out_tex if isinstance(b.out_tex, int) else b.out_tex.value
+    import ctypes
+    tex = r.download(ctypes.c_void_p(base + 16 * local0 * width), np.float32, 4 * width * rows).reshape(-1, 4)
+    rad = lambda t: t[:, :3] / np.maximum(t[:, 3:4], 1)
+    diff = rad(tex).astype(np.float64) - rad(st.out_tex).astype(np.float64)
+    return {"against": "oracle (CPU restatement of the reference's kernels), same RNG streams",
+            "primary_rays": int(n_local), "first_hit_id_mismatches": id_bad, "first_hit_tuv_bit_mismatches": tuv_bad,
+            "primary_rays_that_hit": int((want["t"] != 0).sum()),
+            "radiance_rows": [int(frame_row0), int(frame_row0 + rows)], "radiance_iterations": int(iterations),
+            "radiance_rmse": float(np.sqrt(np.mean(diff ** 2))), "radiance_max_abs_diff": float(np.abs(diff).max()),
+            "radiance_bit_equal": bool((tex.view(np.uint32) == st.out_tex.view(np.uint32)).all()),
+            "radiance_rmse_tolerance": 2e-3}
+
+
 def cpu_baseline(rt, sc, r, width, full_height, threads, cpu_desc, budget_s=12.0, max_iters=96):
     """Oracle (C restatement, OpenMP) on a bounded sample of the same workload:
     the same frame, scene and RNG streams, prepass and the first (null-ray)
@@ -222,6 +271,7 @@ def main():
                     "(they then end at every resolve point, every 50 iterations)")
     ap.add_argument("--size", type=int, default=0, help="override the workload's frame: SIZE x SIZE pixels (tuning runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the parity gates checked after the warm-up")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -305,6 +355,12 @@ def main():
     # reach past the warm-up into the timed iterations, nor past those
     r.spath_render(args.warmup)
     sync_all()
+    parity = None
+    if rank == 0 and not args.no_parity and args.warmup > 0:
+        single = world == 1
+        rows = 16 if single else min(BAND_ROWS, strip)
+        parity = parity_gates(sc, r, width, height, width * strip, (height // 2 - rows // 2) if single else 0, rows,
+                              args.warmup, args.cpu_threads or host_cpu()[0])
     r.timing(True)
     r.timing_reset()
 
@@ -404,6 +460,7 @@ def main():
                          "shade_avg_launch_ms": round(shade_ms / max(launches, 1), 4),
                          "per_ray": {k: round(v, 3) for k, v in per_ray.items()}},
         }
+        out["parity"] = parity
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(rt, sc, r, width, height, threads, cpu_desc)
             out["cpu_baseline"]["value"] = round(out["cpu_baseline"]["value"], 3)

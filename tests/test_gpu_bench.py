@@ -37,6 +37,11 @@ def test_single_process_line():
     assert rf["bound"] == "hbm" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
+    # the gates the number is reported with: every primary ray's first hit and a few rows' radiance against the oracle
+    pg = d["parity"]
+    assert pg["primary_rays"] > 0 and pg["first_hit_id_mismatches"] == 0 and pg["first_hit_tuv_bit_mismatches"] == 0
+    assert 0 < pg["primary_rays_that_hit"] <= pg["primary_rays"]
+    assert pg["radiance_iterations"] == 2 and pg["radiance_bit_equal"] and pg["radiance_rmse"] <= pg["radiance_rmse_tolerance"]
 
 
 def test_two_ranks_render_the_same_frame():
@@ -48,6 +53,9 @@ def test_two_ranks_render_the_same_frame():
                     launcher=launcher)
     assert two["n_gpus"] == 2
     assert two["config"]["frame_crc32"] == one["config"]["frame_crc32"]
+    for d in (one, two):                   # rank 0 checks its own share: the whole frame, or its bands
+        assert d["parity"]["first_hit_id_mismatches"] == 0 and d["parity"]["radiance_bit_equal"]
+    assert two["parity"]["primary_rays"] * 2 == one["parity"]["primary_rays"]
 
 
 def test_plain_invocation_starts_its_own_ranks():
