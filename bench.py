@@ -265,7 +265,7 @@ def main():
     ap.add_argument("--separate-kernels", action="store_true", help="three launches per iteration, as the reference")
     ap.add_argument("--max-batch", type=int, default=None, help="most iterations folded into one launch")
     ap.add_argument("--no-reorder", action="store_true", help="serve pixels in index order in every batch")
-    ap.add_argument("--schedule", type=int, default=None, choices=[0, 1, 2],
+    ap.add_argument("--schedule", type=int, default=None, choices=[0, 1, 2, 3],
                     help="fix the kernel's slot schedule (default: the library's prepass times them)")
     ap.add_argument("--no-run-ahead", action="store_true", help="launches hold only iterations already asked for "
                     "(they then end at every resolve point, every 50 iterations)")
@@ -346,7 +346,7 @@ def main():
         # Every rank timed the kernel's slot schedules on its own share in its prepass; the shares are
         # interleaved bands of one picture, so they should agree, and a rank that a noisy timing sent the other
         # way would set the job's time.  All ranks take the choice most of them made (results do not depend on it).
-        mine = torch.zeros(3, dtype=torch.int64, device=f"cuda:{local_rank}" if backend == "nccl" else "cpu")
+        mine = torch.zeros(4, dtype=torch.int64, device=f"cuda:{local_rank}" if backend == "nccl" else "cpu")
         mine[int(r.spath.contents.schedule)] = 1
         dist.all_reduce(mine)
         r.spath.contents.schedule = int(torch.argmax(mine).item())

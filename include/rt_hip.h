@@ -237,7 +237,10 @@ void rt_k_xorshift(rt_device *dev, rt_mem random, uint32_t n);
                                           would otherwise spill their stacks to memory (unstructured soups), and frames
                                           (or a rank's share of one) with too few pixels to keep every lane busy, where a
                                           batch lasts as long as its heaviest pixel's chain of steps */
-#define RT_SCHEDULE_COUNT          3
+#define RT_SCHEDULE_THREE_AND_THREE 3  /* three and three slots, 16 stack levels in LDS, 4 waves per SIMD: shallow trees
+                                          (tens of thousands of triangles) on small frames, where a batch is a few pixels'
+                                          chains and fewer, longer trips per chain count for more than waves in flight */
+#define RT_SCHEDULE_COUNT          4
 #define RT_RUN_MAX_ITERS     1024u  /* iterations per launch */
 #define RT_RUN_MAX_SNAPSHOTS 32u
 void rt_k_spath_run(rt_device *dev, const rt_kd_view *kd, const rt_spath_buffers *b, uint32_t n, uint32_t iters,

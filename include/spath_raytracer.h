@@ -18,7 +18,7 @@ enum {
                              value of launch k = splitmix32(rng_seed + 1, k); reproducible */
 };
 
-#define RT_TRIAL_PARTS 4   /* timed launches of a calibration: default schedule, two alternatives, default */
+#define RT_TRIAL_PARTS 5   /* timed launches of a calibration: default schedule, three alternatives, default */
 
 typedef struct spath_raytracer_context {
     struct _rt_ctx *rctx;
@@ -68,7 +68,7 @@ typedef struct spath_raytracer_context {
                                             spath_raytracer_calibrate, which times the schedules on this scene and frame */
     int          trial_state;            /* 0: not calibrated yet, 2: decided (kept for later renders of this context) */
     float        trial_ms[RT_TRIAL_PARTS];   /* ms per iteration of the calibration's launches: default schedule, the
-                                                two alternatives, default again */
+                                                three alternatives, default again */
     unsigned int calibration_iterations; /* iterations per calibration launch (0 = 12) */
 
     /* Launches that run ahead of the caller.  A pixel's iterations depend on nothing but the pixel, the iteration

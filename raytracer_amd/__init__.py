@@ -142,7 +142,7 @@ class spath_raytracer_context(C.Structure):
                 ("cl_cost_hist_buffer", C.c_void_p), ("cl_tile_scratch_buffer", C.c_void_p),
                 ("order_valid", C.c_bool), ("no_reorder", C.c_int),
                 ("schedule", C.c_int), ("schedule_fixed", C.c_int), ("trial_state", C.c_int),
-                ("trial_ms", C.c_float * 4), ("calibration_iterations", C.c_uint),
+                ("trial_ms", C.c_float * 5), ("calibration_iterations", C.c_uint),
                 ("run_ahead", C.c_int), ("launched_upto", C.c_uint), ("cl_snapshot_buffer", C.c_void_p),
                 ("snapshot_slots", C.c_uint), ("snap_first_iteration", C.c_uint), ("snap_count", C.c_uint),
                 ("launches", C.c_uint), ("values_uploaded", C.c_void_p * 2)]

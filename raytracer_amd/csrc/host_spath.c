@@ -113,8 +113,10 @@ static void upload_random_buffer(spath_raytracer_context *c)
 
 /* The timed launches of a calibration: the default schedule first and last, the alternatives between. */
 static const int trial_schedule[RT_TRIAL_PARTS] = { RT_SCHEDULE_ONE_LEAF_SLOT, RT_SCHEDULE_TWO_AND_TWO,
-                                                    RT_SCHEDULE_SHORT_CHAINS, RT_SCHEDULE_ONE_LEAF_SLOT };
-static const char *schedule_name[RT_SCHEDULE_COUNT] = { "one and one slot", "two and two slots", "short chains" };
+                                                    RT_SCHEDULE_SHORT_CHAINS, RT_SCHEDULE_THREE_AND_THREE,
+                                                    RT_SCHEDULE_ONE_LEAF_SLOT };
+static const char *schedule_name[RT_SCHEDULE_COUNT] = { "one and one slot", "two and two slots", "short chains",
+                                                        "three and three slots" };
 
 #define RT_ORDER_MIN_PIXELS 65536u     /* smaller frames are served in index order with the default schedule */
 
@@ -285,8 +287,8 @@ void spath_raytracer_calibrate(spath_raytracer_context *c)
         if (t[k] < best) { best = t[k]; c->schedule = trial_schedule[k]; }
     c->trial_state = 2;
     if (!c->quiet)
-        printf("schedule calibration: %.3f / %.3f / %.3f / %.3f ms per iteration -> %s\n", t[0], t[1], t[2], t[3],
-               schedule_name[c->schedule]);
+        printf("schedule calibration: %.3f / %.3f / %.3f / %.3f / %.3f ms per iteration -> %s\n", t[0], t[1], t[2], t[3],
+               t[4], schedule_name[c->schedule]);
 }
 
 /* The reference's two debug views (commented out of its render loop, src/spath_raytracer.c:400): the current rays'

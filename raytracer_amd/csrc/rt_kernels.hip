@@ -1456,6 +1456,10 @@ void launch_spath_run(rt_device *dev, const TravScene &P, const SpathDev &B, uin
         launch_run_variant<16, 16, 64, 2, 2, 5>(dev, P, B, n, iters, rv, snap_first, snap_every);
         return;
     }
+    if (variant == 0 && schedule == RT_SCHEDULE_THREE_AND_THREE) {
+        launch_run_variant<16, 16, 64, 3, 3, 4>(dev, P, B, n, iters, rv, snap_first, snap_every);
+        return;
+    }
     switch (variant) {
     case 1: launch_run_variant<10, 16, 64, 2, 1, 7>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
     case 2: launch_run_variant<10, 8, 64, 1, 1, 7>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
@@ -1483,7 +1487,7 @@ void launch_spath_run(rt_device *dev, const TravScene &P, const SpathDev &B, uin
     case 25: launch_run_variant<16, 16, 64, 2, 2, 4>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
     case 26: launch_run_variant<16, 16, 64, 2, 2, 3>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
     case 27: launch_run_variant<16, 16, 64, 1, 1, 4>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
-    case 28: launch_run_variant<16, 16, 64, 3, 3, 4>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
+    case 28: launch_run_variant<16, 16, 64, 3, 3, 4>(dev, P, B, n, iters, rv, snap_first, snap_every); break;   // = RT_SCHEDULE_THREE_AND_THREE
     default: launch_run_variant<10, 16, 64, 1, 1, 7>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
     }
 }

@@ -157,7 +157,7 @@ def test_config5_size_strip_against_oracle(rt, orc):
     (11 M nodes, 30 M leaf slots), long leaves, every slot schedule, against the oracle."""
     sc = rt.scenes.soup_scene(10_000_000)
     w, full_h, y0, rows, iters = 3840, 2160, 1078, 4, 5
-    for schedule in (1, 0, 2):
+    for schedule in (1, 0, 2, 3):
         r = rt.Renderer(sc, w, rows, tile_y0=y0, full_height=full_h).build()
         r.init_spath(seed=8, resolve_interval=0, quiet=True, schedule=schedule)
         r.spath_prepass(num_iterations=1 << 30)

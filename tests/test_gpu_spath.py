@@ -215,7 +215,7 @@ def test_frames_at_resolve_points_when_launches_run_ahead(rt, orc, small, size, 
     r.close()
 
 
-@pytest.mark.parametrize("schedule", [0, 1, 2])
+@pytest.mark.parametrize("schedule", [0, 1, 2, 3])
 def test_deep_stack_scene_bit_exact(rt, orc, schedule):
     """Rays through an 82k-triangle mesh need more stack levels than the LDS part
     holds (the reference's own limit is 16): the spill path must agree too, under
@@ -238,7 +238,7 @@ def test_deep_stack_scene_bit_exact(rt, orc, schedule):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("schedule", [0, 1, 2])
+@pytest.mark.parametrize("schedule", [0, 1, 2, 3])
 def test_long_leaves_bit_exact(rt, orc, schedule):
     """Leaves of 45 and 33 triangles (stacks of coincident ones): more than a leaf descriptor's count field holds, so
     the walk reads the count from the leaf's header slot; of a stack the first triangle in stored order is reported,
