@@ -97,9 +97,10 @@ def oracle_tree(sc, r):
 
 
 def parity_gates(sc, r, width, full_height, n_local, frame_row0, rows, iterations, threads):
-    """The gates a number is reported with, checked on the state the device holds after the warm-up iterations
-    against the oracle (CPU restatement): (1) the first hit of EVERY primary ray of this rank's pixels -- triangle
-    index and the bits of t, u, v; (2) the accumulated radiance of `rows` frame rows from `frame_row0` (this rank's
+    """The gates a number is reported with, checked AFTER the timed region on the state the device then holds
+    (warm-up + timed iterations) against the oracle (CPU restatement): (1) the first hit of EVERY primary ray of
+    this rank's pixels -- triangle index and the bits of t, u, v (primary rays and hits are saved by the prepass and
+    never change during a render); (2) the accumulated radiance of `rows` frame rows from `frame_row0` (this rank's
     first pixels when they are a band, the middle of the picture otherwise) after the same `iterations` iterations
     with the same RNG streams.  Returns the `parity` object of the bench line."""
     import oracle
@@ -270,8 +271,10 @@ def main():
     ap.add_argument("--no-run-ahead", action="store_true", help="launches hold only iterations already asked for "
                     "(they then end at every resolve point, every 50 iterations)")
     ap.add_argument("--size", type=int, default=0, help="override the workload's frame: SIZE x SIZE pixels (tuning runs)")
+    ap.add_argument("--repeats", type=int, default=1, help="timed regions of --steps iterations each, one after "
+                    "another; the median is reported (config.repeats, config.timed_regions_ms)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-parity", action="store_true", help="skip the parity gates checked after the warm-up")
+    ap.add_argument("--no-parity", action="store_true", help="skip the parity gates checked after the timed region")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -305,6 +308,10 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    if world > 1:
+        # every rank builds the same tree: each takes its share of this job's host cores instead of all of them
+        # (read by the OpenMP runtime when the library is loaded, below)
+        os.environ["OMP_NUM_THREADS"] = str(max(1, host_cpu()[0] // world))
     import raytracer_amd as rt
 
     spec, width, height, desc = WORKLOADS[args.workload]
@@ -313,7 +320,7 @@ def main():
         desc += f" [frame overridden: {width}x{height}]"
     # Interleaved bands of rows: every rank gets rows from all over the frame, so the expensive centre of the
     # picture is shared out evenly (contiguous strips of this scene differ by 2x in cost).
-    from raytracer_amd.strips import BAND_ROWS, band_partition
+    from raytracer_amd.strips import BAND_ROWS, band_frame_index, band_partition, band_share_sizes
     try:
         first, band, stride, strip = band_partition(height, world, rank)
     except ValueError as e:
@@ -351,59 +358,62 @@ def main():
         dist.all_reduce(mine)
         r.spath.contents.schedule = int(torch.argmax(mine).item())
         r.spath.contents.schedule_fixed = 1
-    # Renderer.spath_render ends the render where its calls end while they run, so the library's launches never
-    # reach past the warm-up into the timed iterations, nor past those
-    r.spath_render(args.warmup)
-    sync_all()
-    parity = None
-    if rank == 0 and not args.no_parity and args.warmup > 0:
-        single = world == 1
-        rows = 16 if single else min(BAND_ROWS, strip)
-        try:
-            parity = parity_gates(sc, r, width, height, width * strip, (height // 2 - rows // 2) if single else 0, rows,
-                                  args.warmup, args.cpu_threads or host_cpu()[0])
-        except Exception as e:              # the checker must not cost the benchmark its line: say that it did not run
-            log(f"[bench] parity gates not checked: {e!r}")
-            parity = {"error": repr(e)}
-    r.timing(True)
-    r.timing_reset()
-
     n_local = width * strip
-    frame = None
+    frame = wire = gathered = None
+    shares = band_share_sizes(width, height, world) if world > 1 else [n_local]
+    pad = max(shares)
     if torch is not None:
-        frame = torch.empty(n_local, dtype=torch.int32, device=f"cuda:{local_rank}")
-        wire = frame if backend == "nccl" else torch.empty(n_local, dtype=torch.int32)    # gloo moves host tensors
-        gathered = [torch.empty_like(wire) for _ in range(world)] if rank == 0 else None
+        # one preallocated [world, pad] tensor on rank 0 takes the gather; shares are padded to the largest
+        frame = torch.zeros(pad, dtype=torch.int32, device=f"cuda:{local_rank}")
+        wire = frame if backend == "nccl" else torch.zeros(pad, dtype=torch.int32)    # gloo moves host tensors
+        gathered = torch.empty((world, pad), dtype=torch.int32, device=wire.device) if rank == 0 else None
 
     def gather_frame():
-        # resolve this strip, hand it to torch and gather the frame on rank 0 (RCCL)
+        # resolve this rank's rows, hand them to torch and gather the frame on rank 0 (RCCL)
         r.L.rt_k_resolve_avg(r.dev, r.rctx.contents.cl_output_buffer, r.spath.contents.cl_path_output_buffer, n_local)
         r.L.rt_mem_copy(r.dev, frame.data_ptr(), r.rctx.contents.cl_output_buffer, n_local * 4)
         r.sync()
+        t_copied = time.perf_counter()
         if wire is not frame:
             wire.copy_(frame)
-        dist.gather(wire, gathered, dst=0)
+        dist.gather(wire, list(gathered.unbind(0)) if rank == 0 else None, dst=0)
+        return t_copied
 
+    # Renderer.spath_render ends the render where its calls end while they run, so the library's launches never
+    # reach past the warm-up into the timed iterations, nor past those.  Nothing but the barrier lies between the
+    # warm-up launch and the timed one: the parity gates (seconds of CPU work) are checked after the timed region,
+    # so the timed launch starts on a GPU that has just been busy, at the clocks a render runs at.
+    r.spath_render(args.warmup)
     if torch is not None:
         gather_frame()      # part of the warm-up: the first gather sets up the point-to-point connections it uses
     sync_all()
-    t0 = time.perf_counter()
-    r.spath_render(args.steps)
-    if os.environ.get("RT_BENCH_TRACE") and torch is not None:      # where the timed region's tail goes
-        r.sync(); ta = time.perf_counter()
-        gather_frame(); tb = time.perf_counter()
-        r.sync(); torch.cuda.synchronize(); tc = time.perf_counter()
-        dist.barrier(); td = time.perf_counter()
-        log(f"[bench trace] rank {rank}: render {1e3 * (ta - t0):.3f} ms, resolve+gather {1e3 * (tb - ta):.3f}, "
-            f"sync {1e3 * (tc - tb):.3f}, barrier {1e3 * (td - tc):.3f}")
-    elif torch is not None:
-        gather_frame()
-    sync_all()
-    dt = time.perf_counter() - t0
+    r.timing(True)
+    r.timing_reset()
+
+    regions, split = [], None
+    for rep in range(args.repeats):
+        sync_all()
+        t0 = time.perf_counter()
+        r.spath_render(args.steps)
+        if torch is not None:
+            r.sync(); ta = time.perf_counter()                  # render (this rank's launch has ended)
+            tb = gather_frame(); tc = time.perf_counter()       # resolve + copy | gather
+            sync_all(); td = time.perf_counter()                # barrier: the job ends when its slowest rank does
+            split = [1e3 * (ta - t0), 1e3 * (tb - ta), 1e3 * (tc - tb), 1e3 * (td - tc)]
+        else:
+            sync_all()
+        regions.append(time.perf_counter() - t0)
     if torch is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        t = torch.tensor(regions + split, dtype=torch.float64, device=f"cuda:{local_rank}" if backend == "nccl" else "cpu")
+        every = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(every, t)
+        every = torch.stack(every).cpu().numpy()
+        regions = [float(x) for x in every[:, :args.repeats].max(axis=0)]       # MAX over ranks, per timed region
+        rank_split = every[:, args.repeats:]
+    else:
+        rank_split = None
+    dt = float(np.median(regions))
+    done_iterations = args.warmup + args.repeats * args.steps
 
     # dominant kernel: the multi-iteration launch (traversal + shading of a batch of
     # iterations), or the traversal launch when iterations are launched one by one
@@ -416,14 +426,28 @@ def main():
     # its checksum goes into the line so runs at different N can be compared.
     import zlib
     if torch is not None:
-        if rank == 0:       # bands back into frame order: [rank, band of the rank, pixels] -> [band, rank, pixels]
-            whole = torch.stack(gathered).view(world, strip // band, band * width).transpose(0, 1).reshape(-1)
+        if rank == 0:       # the ranks' bands back into frame order
+            whole = gathered.reshape(-1)[band_frame_index(width, height, world).to(gathered.device)]
             frame_crc = zlib.crc32(whole.cpu().numpy().tobytes())
         else:
             frame_crc = 0
     else:
         frame_crc = zlib.crc32(r.spath_resolve().tobytes())
 
+    parity, parity_ok = None, None
+    if rank == 0 and not args.no_parity:
+        single = world == 1
+        rows = min(16 if single else BAND_ROWS, strip)
+        try:
+            parity = parity_gates(sc, r, width, height, n_local, (height // 2 - rows // 2) if single else 0, rows,
+                                  done_iterations, args.cpu_threads or host_cpu()[0])
+            parity_ok = (parity["first_hit_id_mismatches"] == 0 and parity["first_hit_tuv_bit_mismatches"] == 0
+                         and parity["radiance_rmse"] <= parity["radiance_rmse_tolerance"])
+        except Exception as e:              # a checker that could not run is reported as such; the line says so
+            log(f"[bench] parity gates not checked: {e!r}")
+            parity = {"error": repr(e)}
+
+    exit_code = 0
     if rank == 0:
         total_rays = width * height * args.steps
         value = total_rays / dt / 1e6
@@ -432,15 +456,20 @@ def main():
         per_ray, b_gather = gather_stats(rt, sc, r, threads)
         b_ray = B_STREAM + b_gather
         avg_ms = kms / max(launches, 1)
-        iters_per_launch = args.steps / max(launches, 1)      # 1 with --separate-kernels
+        iters_per_launch = args.repeats * args.steps / max(launches, 1)      # 1 with --separate-kernels
         rays_per_launch = n_local * iters_per_launch
         achieved = (b_ray * rays_per_launch) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic = None                 # HBM bytes per launch from the PMC passes (profiles/pmc_passes.sh), if recorded
+        # HBM bytes per launch and what limits the kernel, from the stored rocprofv3 --pmc passes of this workload
+        # (profiles/pmc_passes.sh; a profiler cannot run inside this process): scaled by this run's iterations
+        traffic = counter_frac = None
+        limiter = {}
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                per_iter = json.load(open(tpath))[f"{args.workload}:{kname}"]["hbm_bytes_per_iteration"]
-                traffic = round(per_iter * iters_per_launch * n_local / (width * height))
+                rec = json.load(open(tpath))[f"{args.workload}:{kname}"]
+                traffic = round(rec["hbm_bytes_per_iteration"] * iters_per_launch * n_local / (width * height))
+                counter_frac = round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if avg_ms > 0 else None
+                limiter = {k: rec[k] for k in ("limiter", "valu_insts_per_ray", "useful_lane_frac", "profile") if k in rec}
             except Exception:
                 traffic = None
         out = {
@@ -449,15 +478,23 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32",
             "data": "reference mesh files (frozen in tests/golden/c2obj_scene.npz), synthetic RNG streams" if spec[0] == "npz" else "synthetic",
+            "parity_ok": parity_ok,
             "config": {"workload": f"{args.workload}: {desc}", "triangles": int(sc.num_tris), "width": width,
                        "height": height, "rows_per_gpu": strip, "kernel": kname,
                        "schedule": int(r.spath.contents.schedule),
                        "schedule_calibration_ms_per_iteration": [round(float(x), 4) for x in r.spath.contents.trial_ms]
                        if int(r.spath.contents.trial_state) == 2 else None,
                        "run_ahead": not args.no_run_ahead, "frame_crc32": f"{frame_crc:08x}",
-                       "partition": f"{BAND_ROWS}-row bands dealt to {world} ranks + RCCL gather of the resolved frame" if world > 1 else "single GPU"},
+                       "frame_after_iterations": done_iterations,
+                       "repeats": args.repeats,
+                       "timed_regions_ms": [round(1e3 * x, 3) for x in regions],
+                       "partition": f"{BAND_ROWS}-row bands dealt to {world} ranks ({min(shares) // width}-{max(shares) // width} rows "
+                                    f"each) + RCCL gather of the resolved frame" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_source": "profiles/traffic.json: FETCH_SIZE + WRITE_SIZE of rocprofv3 --pmc passes over this "
+                                           "workload's launch, scaled to this run's iterations per launch -- not measured in this run",
+                         "counter_frac": counter_frac, **limiter,
                          "kernel": kname, "avg_launch_ms": round(avg_ms, 4), "launches": launches,
                          "bytes_per_ray": round(b_ray, 1), "rays_per_launch": int(rays_per_launch),
                          "iterations_per_launch": round(iters_per_launch, 2),
@@ -465,6 +502,11 @@ def main():
                          "per_ray": {k: round(v, 3) for k, v in per_ray.items()}},
         }
         out["parity"] = parity
+        if rank_split is not None:
+            # where each rank's share of the last timed region went (host clock, ms)
+            out["ranks"] = [{"rank": k, "rows": shares[k] // width, "render_ms": round(float(v[0]), 3),
+                             "resolve_copy_ms": round(float(v[1]), 3), "gather_ms": round(float(v[2]), 3),
+                             "barrier_ms": round(float(v[3]), 3)} for k, v in enumerate(rank_split)]
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(rt, sc, r, width, height, threads, cpu_desc)
             out["cpu_baseline"]["value"] = round(out["cpu_baseline"]["value"], 3)
@@ -475,12 +517,20 @@ def main():
                 ref = None
             if ref is not None:
                 out["reference_gpu"] = ref
+        if parity_ok is False:
+            # a gate that ran and failed: the number does not stand for the reference's computation
+            log(f"[bench] PARITY GATE FAILED: {parity}")
+            out["value_unchecked"] = out["value"]
+            out["value"] = None
+            exit_code = 3
         os.write(json_fd, (json.dumps(out) + "\n").encode())
 
     if torch is not None:
         dist.barrier()
         dist.destroy_process_group()
     r.close()
+    if exit_code:
+        sys.exit(exit_code)
 
 
 if __name__ == "__main__":

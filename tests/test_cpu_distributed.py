@@ -71,14 +71,28 @@ def _band_worker(rank, world, port, w, h, out_path):
     dist.destroy_process_group()
 
 
-def test_two_rank_band_gather_restores_frame_order(tmp_path):
+@pytest.mark.parametrize("w,h,world", [(5, 48, 2), (3, 56, 3), (2, 61, 3), (1, 2160, 4), (1, 2160, 8)])
+def test_band_gather_restores_frame_order(tmp_path, w, h, world):
+    """Even and ragged shares (bands not a multiple of the ranks, a short last band), up to the 2160 rows of the
+    3840x2160 configuration on 4 and 8 ranks: the gathered frame is in row order."""
     import torch.multiprocessing as mp
-    from raytracer_amd.strips import band_partition, band_rows
-    w, h, world = 5, 48, 2
     out = str(tmp_path / "bands.npy")
     mp.spawn(_band_worker, args=(world, _free_port(), w, h, out), nprocs=world, join=True)
     assert np.array_equal(np.load(out), np.arange(w * h, dtype=np.int32))
+
+
+def test_band_partition_shares():
+    from raytracer_amd.strips import band_partition, band_rows
     assert band_partition(48, 2, 1) == (8, 8, 16, 24)
     assert band_rows(32, 2, 1)[:9] == [8, 9, 10, 11, 12, 13, 14, 15, 24]
+    # 2160 rows = 270 bands: six ranks of eight hold 34 bands, two hold 33
+    assert [band_partition(2160, 8, r)[3] for r in range(8)] == [272] * 6 + [264] * 2
+    assert [band_partition(2160, 4, r)[3] for r in range(4)] == [544, 544, 536, 536]
+    # a short last band belongs to the rank whose turn it is
+    assert [band_partition(50, 2, r)[3] for r in range(2)] == [26, 24]
+    assert band_rows(50, 2, 0)[-3:] == [39, 48, 49]
+    for h, world in [(2160, 8), (2160, 4), (56, 3), (61, 3), (9, 2), (2048, 8)]:
+        rows = sorted(y for r in range(world) for y in band_rows(h, world, r))
+        assert rows == list(range(h))
     with pytest.raises(ValueError):
-        band_partition(50, 2, 0)
+        band_partition(8, 2, 0)        # one band, two ranks

@@ -41,7 +41,19 @@ def test_single_process_line():
     pg = d["parity"]
     assert pg["primary_rays"] > 0 and pg["first_hit_id_mismatches"] == 0 and pg["first_hit_tuv_bit_mismatches"] == 0
     assert 0 < pg["primary_rays_that_hit"] <= pg["primary_rays"]
-    assert pg["radiance_iterations"] == 2 and pg["radiance_bit_equal"] and pg["radiance_rmse"] <= pg["radiance_rmse_tolerance"]
+    # checked after the timed region, on the state after warm-up + timed iterations
+    assert pg["radiance_iterations"] == 8 and pg["radiance_bit_equal"] and pg["radiance_rmse"] <= pg["radiance_rmse_tolerance"]
+    assert d["parity_ok"] is True
+    assert rf["traffic_source"] and "counter_frac" in rf
+
+
+def test_repeats_report_the_median_region():
+    d = run_bench(["--workload", "tiny", "--steps", "6", "--warmup", "2", "--repeats", "3", "--no-cpu-baseline"])
+    c = d["config"]
+    assert c["repeats"] == 3 and len(c["timed_regions_ms"]) == 3 and c["frame_after_iterations"] == 20
+    assert abs(d["ms_per_step"] * 6 - sorted(c["timed_regions_ms"])[1]) < 1e-2
+    assert d["roofline"]["launches"] == 3 and d["roofline"]["iterations_per_launch"] == 6
+    assert d["parity"]["radiance_iterations"] == 20 and d["parity_ok"] is True
 
 
 def test_two_ranks_render_the_same_frame():
@@ -56,6 +68,20 @@ def test_two_ranks_render_the_same_frame():
     for d in (one, two):                   # rank 0 checks its own share: the whole frame, or its bands
         assert d["parity"]["first_hit_id_mismatches"] == 0 and d["parity"]["radiance_bit_equal"]
     assert two["parity"]["primary_rays"] * 2 == one["parity"]["primary_rays"]
+    assert [k["rows"] for k in two["ranks"]] == [128, 128] and all(k["render_ms"] > 0 for k in two["ranks"])
+
+
+def test_three_ranks_with_ragged_shares_render_the_same_frame():
+    """256 rows are 32 bands: three ranks hold 11, 11 and 10 of them; the gathered frame is the single-rank one."""
+    args = ["--workload", "tiny", "--steps", "6", "--warmup", "2", "--no-cpu-baseline"]
+    one = run_bench(args)
+    launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3",
+                "--master-addr", "127.0.0.1", "--master-port", "29535"]
+    three = run_bench(["--gpus", "3"] + args, env_extra={"RT_BENCH_BACKEND": "gloo", "RT_BENCH_SHARE_GPU": "1"},
+                      launcher=launcher)
+    assert three["n_gpus"] == 3 and [k["rows"] for k in three["ranks"]] == [88, 88, 80]
+    assert three["config"]["frame_crc32"] == one["config"]["frame_crc32"]
+    assert three["parity_ok"] is True
 
 
 def test_plain_invocation_starts_its_own_ranks():

@@ -108,11 +108,14 @@ def test_tile_equals_full_frame(rt, orc, small):
     assert_bits_equal(got.reshape(-1, 4), st.out_tex, "strip vs oracle strip")
 
 
-def test_interleaved_bands_equal_full_frame(rt, orc, small):
-    """Rows dealt to 3 ranks in bands of 8: each rank's pixels are the full frame's pixels of those rows."""
+@pytest.mark.parametrize("h", [48, 56, 61])
+def test_interleaved_bands_equal_full_frame(rt, orc, small, h):
+    """Rows dealt to 3 ranks in bands of 8: each rank's pixels are the full frame's pixels of those rows.  48 rows
+    give every rank two bands; 56 rows are seven bands (shares of 3, 2 and 2 bands); 61 rows end in a band of five
+    rows (shares of 24, 21 and 16 rows)."""
     from raytracer_amd.strips import band_partition, band_rows
     sc, tree = small
-    w, h, iters, seed, world = 64, 48, 6, 7, 3
+    w, iters, seed, world = 64, 6, 7, 3
     full = rt.Renderer(sc, w, h).build()
     full.init_spath(seed=seed, resolve_interval=0)
     full.spath_prepass(iters)
