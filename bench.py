@@ -502,6 +502,19 @@ def main():
                          "per_ray": {k: round(v, 3) for k, v in per_ray.items()}},
         }
         out["parity"] = parity
+        # the target render (256 samples x 4 bounces = 1024 iterations) against the reference's own kernels on this
+        # GPU model: a stored, dated figure of tests/tools/ref_kernels_parity.py (minutes of run time), quoted here
+        quoted = os.path.join(ROOT, "profiles", "r02", f"{args.workload}_full_size_parity_1024_iterations.json")
+        if isinstance(parity, dict) and os.path.exists(quoted):
+            try:
+                q = json.load(open(quoted))
+                parity["quoted_full_render_vs_reference_kernels"] = {
+                    "source": os.path.relpath(quoted, ROOT), "measured": "round 2 (2026-11), not in this run",
+                    "iterations": q["iterations"], "radiance_rmse": q["radiance_rmse"],
+                    "pixels_left_out_reference_stack_overflow": q["pixels_left_out"],
+                    "pixels_within_1e-3": q["pixels_within_1e-3"]}
+            except Exception:
+                pass
         if rank_split is not None:
             # where each rank's share of the last timed region went (host clock, ms)
             out["ranks"] = [{"rank": k, "rows": shares[k] // width, "render_ms": round(float(v[0]), 3),

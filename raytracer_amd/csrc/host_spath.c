@@ -79,7 +79,7 @@ spath_raytracer_context *init_spath_raytracer_context(struct _rt_ctx *rctx)
     c->pending = 0;
     c->pending_values = (unsigned int *)rt_host_alloc(dev, sizeof(unsigned int) * 2 * RT_RUN_MAX_ITERS);
     c->cl_random_value_buffer = rt_mem_alloc(dev, sizeof(unsigned int) * 2 * RT_RUN_MAX_ITERS);
-    c->cl_pixel_cost_buffer = rt_mem_alloc(dev, ((size_t)n + 65536) * sizeof(unsigned int));   /* + room for a diagnostic build's per-wave time stamps */
+    c->cl_pixel_cost_buffer = rt_mem_alloc(dev, ((size_t)n + 131072) * sizeof(unsigned int));   /* + room for a diagnostic build's per-wave time stamps */
     c->cl_pixel_order_buffer = rt_mem_alloc(dev, n * sizeof(unsigned int));
     c->cl_cost_hist_buffer = rt_mem_alloc(dev, 256 * sizeof(unsigned int));
     /* whole 8x8 screen tiles are ordered when the frame divides into them */

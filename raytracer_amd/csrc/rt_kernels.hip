@@ -852,8 +852,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
     bool plain = false;
     uint32_t mode = FREE, pix = 0, it = 0, rnd = 0, steps = 0;
 #ifdef RT_WAVE_TIMES
-    if (threadIdx.x == 0 && blockIdx.x < 16384) B.cost[n + 4 * blockIdx.x] = (uint32_t)__builtin_amdgcn_s_memrealtime();
-    uint32_t exhausted_at = 0, trips = 0;
+    // diagnostic build: per wave, the constant 100 MHz clock (s_memrealtime) and the shader clock counter (s_memtime)
+    // at its start, when it finds the work counter dry, and at its exit; their ratio is the shader clock it ran at
+    if (threadIdx.x == 0 && blockIdx.x < 8192) {
+        B.cost[n + 8 * blockIdx.x] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+        B.cost[n + 8 * blockIdx.x + 4] = (uint32_t)__builtin_amdgcn_s_memtime();
+    }
+    uint32_t exhausted_at = 0, exhausted_clk = 0, trips = 0;
 #endif
     float4 pa = make_float4(0, 0, 0, 0), pb = pa;
 
@@ -914,7 +919,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         }
 #ifdef RT_WAVE_TIMES
         trips++;
-        if (q.exhausted && !exhausted_at) exhausted_at = (uint32_t)__builtin_amdgcn_s_memrealtime();
+        // every 2^RT_WAVE_MILESTONE_SHIFT-th trip of the first 1024 waves: both clocks (32 milestones per wave, behind the per-wave records)
+#ifndef RT_WAVE_MILESTONE_SHIFT
+#define RT_WAVE_MILESTONE_SHIFT 10
+#endif
+        if ((trips & ((1u << RT_WAVE_MILESTONE_SHIFT) - 1u)) == 0u && (trips >> RT_WAVE_MILESTONE_SHIFT) <= 32u && blockIdx.x < 1024 && threadIdx.x == 0) {
+            uint32_t *m = B.cost + n + 65536 + 64 * blockIdx.x + 2 * ((trips >> RT_WAVE_MILESTONE_SHIFT) - 1u);
+            m[0] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+            m[1] = (uint32_t)__builtin_amdgcn_s_memtime();
+        }
+        if (q.exhausted && !exhausted_at) {
+            exhausted_at = (uint32_t)__builtin_amdgcn_s_memrealtime();
+            exhausted_clk = (uint32_t)__builtin_amdgcn_s_memtime();
+        }
 #endif
         if (!__any(mode == WALK)) {
             if (q.exhausted && !__any(mode == DONE)) break;
@@ -946,10 +963,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         }
     }
 #ifdef RT_WAVE_TIMES
-    if (threadIdx.x == 0 && blockIdx.x < 16384) {
-        B.cost[n + 4 * blockIdx.x + 1] = (uint32_t)__builtin_amdgcn_s_memrealtime();
-        B.cost[n + 4 * blockIdx.x + 2] = exhausted_at;
-        B.cost[n + 4 * blockIdx.x + 3] = trips;
+    if (threadIdx.x == 0 && blockIdx.x < 8192) {
+        B.cost[n + 8 * blockIdx.x + 1] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+        B.cost[n + 8 * blockIdx.x + 2] = exhausted_at;
+        B.cost[n + 8 * blockIdx.x + 3] = trips;
+        B.cost[n + 8 * blockIdx.x + 5] = (uint32_t)__builtin_amdgcn_s_memtime();
+        B.cost[n + 8 * blockIdx.x + 6] = exhausted_clk;
     }
 #endif
 }
