@@ -194,15 +194,18 @@ void rt_k_kd_intersect(rt_device *dev, const rt_kd_view *kd, rt_mem ray_o, rt_me
 /* rt_k_kd_intersect for callers that cannot allocate device memory (code under
    HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  No
    counterpart in the reference.  Same kernel, same results, but the work counter
-   lives in a 512-byte array inside the library's code object (one copy per GPU,
+   lives in an 8 KB array inside the library's code object (one copy per GPU,
    resolved when the rt_device is opened) instead of memory the library
    allocates, and the call itself allocates nothing: no hipMalloc / hipFree, no
    event creation (rt_timing_* does not see it), fixed launch parameters.
    At most RT_NOALLOC_MAX_RAYS rays per call.  Returns 0 when the launch is
    queued; non-zero, with a message on stderr and nothing launched, when n is
-   over the limit (1) or the tree or a buffer is missing (2).  All rt_devices
-   opened on one GPU share that GPU's array (one counter line per stream index):
-   calls that overlap on one GPU with the same stream index race -- order them. */
+   over the limit (1), the tree or a buffer is missing (2), or this rt_device got
+   no counter lines because 16 other rt_devices were open on the same GPU when
+   it was opened (3).  Every rt_device holds its own counter lines of its GPU's
+   array (one per stream index) from rt_device_open to rt_device_close, so calls
+   through different rt_devices, or on different streams of one, may overlap;
+   two calls on the same stream are ordered by the stream. */
 #define RT_NOALLOC_MAX_RAYS 0x80000000u
 int rt_k_kd_intersect_noalloc(rt_device *dev, const rt_kd_view *kd, rt_mem ray_o, rt_mem ray_d, rt_mem hits, uint32_t n);
 

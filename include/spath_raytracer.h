@@ -18,6 +18,7 @@ enum {
                              value of launch k = splitmix32(rng_seed + 1, k); reproducible */
 };
 
+#define RT_SPAN_MAX 64      /* render launches whose device time is pending between two resolve-point lines */
 #define RT_TRIAL_PARTS 5   /* timed launches of a calibration: default schedule, three alternatives, default */
 
 typedef struct spath_raytracer_context {
@@ -87,6 +88,13 @@ typedef struct spath_raytracer_context {
     unsigned int snap_count;
     unsigned int launches;               /* rt_k_spath_run launches since the prepass (diagnostic) */
     rt_event     values_uploaded[2];     /* marker behind the last upload from each of the two value tables */
+    /* Device time of this context's own render launches since the last line printed at a resolve point (quiet == false
+       only): marker pairs around each launch on the device's stream, summed when the line is printed.  The device-wide
+       rt_timing_* table is left to whoever else uses the rt_device. */
+    rt_event     span_marks[2 * RT_SPAN_MAX];
+    unsigned int span_count;             /* pairs not summed yet */
+    unsigned int span_launches;          /* launches summed into span_ms */
+    double       span_ms;
 } spath_raytracer_context;
 
 spath_raytracer_context *init_spath_raytracer_context(struct _rt_ctx *rctx);   /* src/spath_raytracer.c:39-116 */
@@ -98,8 +106,15 @@ void spath_raytracer_kd_test(spath_raytracer_context *ctx);                     
 /* not in the reference */
 void spath_raytracer_flush(spath_raytracer_context *ctx);     /* launch whatever render calls are still pending */
 void spath_raytracer_resolve(spath_raytracer_context *ctx);   /* flush, then resolve the accumulator as the device holds it
-                                                                  (with run_ahead that may be ahead of current_iteration)
-                                                                  + blocking readback into output_buffer */
+                                                                  + blocking readback into output_buffer.  Fatal when
+                                                                  launches have run ahead of current_iteration (the
+                                                                  frame would hold iterations the caller has not asked
+                                                                  for): between resolve points use run_ahead = 0, or end
+                                                                  the render at the iteration wanted (num_iterations)
+                                                                  before it is launched */
+/* Also fatal, for the same reason: a spath_raytracer_render call that finds num_iterations lowered below launched_upto,
+   or separate_kernels switched on while launched_upto is ahead of current_iteration.  Set both before the first render
+   call after a prepass (or render with run_ahead = 0). */
 /* Times the kernel's slot schedules (RT_SCHEDULE_*) on this scene and frame and keeps the fastest in ctx->schedule.
    Called by spath_raytracer_prepass when schedule_fixed is 0 and no decision exists yet; needs the state a prepass
    leaves.  Runs a few throw-away iterations on the per-pixel buffers and puts them back exactly (copies taken

@@ -145,7 +145,9 @@ class spath_raytracer_context(C.Structure):
                 ("trial_ms", C.c_float * 5), ("calibration_iterations", C.c_uint),
                 ("run_ahead", C.c_int), ("launched_upto", C.c_uint), ("cl_snapshot_buffer", C.c_void_p),
                 ("snapshot_slots", C.c_uint), ("snap_first_iteration", C.c_uint), ("snap_count", C.c_uint),
-                ("launches", C.c_uint), ("values_uploaded", C.c_void_p * 2)]
+                ("launches", C.c_uint), ("values_uploaded", C.c_void_p * 2),
+                ("span_marks", C.c_void_p * 128), ("span_count", C.c_uint), ("span_launches", C.c_uint),
+                ("span_ms", C.c_double)]
 
 
 class rt_device_props(C.Structure):
@@ -169,6 +171,7 @@ _ABI_OFFSETS = [("raytracer_context", "stat_scene"), ("raytracer_context", "rcl"
                 ("spath_raytracer_context", "cl_random_value_buffer"), ("spath_raytracer_context", "no_reorder"),
                 ("spath_raytracer_context", "trial_ms"), ("spath_raytracer_context", "run_ahead"),
                 ("spath_raytracer_context", "cl_snapshot_buffer"), ("spath_raytracer_context", "launches"),
+                ("spath_raytracer_context", "span_ms"),
                 ("path_raytracer_context", "cl_path_output_buffer")]
 
 # every symbol the headers under include/ declare

@@ -34,6 +34,7 @@ size_t rt_abi_query(const char *name)
     OFFSET_OF(spath_raytracer_context, cl_random_value_buffer); OFFSET_OF(spath_raytracer_context, no_reorder);
     OFFSET_OF(spath_raytracer_context, trial_ms); OFFSET_OF(spath_raytracer_context, run_ahead);
     OFFSET_OF(spath_raytracer_context, cl_snapshot_buffer); OFFSET_OF(spath_raytracer_context, launches);
+    OFFSET_OF(spath_raytracer_context, span_ms);
     OFFSET_OF(path_raytracer_context, cl_path_output_buffer);
     OFFSET_OF(mesh, material_index); OFFSET_OF(material, reflectivity);
     OFFSET_OF(sphere, material_index); OFFSET_OF(plane, material_index);

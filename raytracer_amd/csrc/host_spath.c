@@ -145,6 +145,41 @@ static void update_pixel_order(spath_raytracer_context *c, unsigned int cost_ite
     c->order_valid = true;
 }
 
+/* Device time of this context's render launches (for the line printed at the resolve points of a context that is
+   not quiet): a marker pair around each launch, summed here.  fold waits for the last pair's launch to end. */
+static void span_fold(spath_raytracer_context *c)
+{
+    rt_device *dev = c->rctx->rcl->device;
+    for (unsigned int k = 0; k < c->span_count; k++) {
+        c->span_ms += rt_event_elapsed_ms(dev, c->span_marks[2 * k], c->span_marks[2 * k + 1]);
+        c->span_launches++;
+        rt_event_release(dev, c->span_marks[2 * k]);
+        rt_event_release(dev, c->span_marks[2 * k + 1]);
+    }
+    c->span_count = 0;
+}
+
+static void span_begin(spath_raytracer_context *c)
+{
+    if (c->quiet) return;
+    if (c->span_count == RT_SPAN_MAX) span_fold(c);
+    c->span_marks[2 * c->span_count] = rt_event_record(c->rctx->rcl->device);
+}
+
+static void span_end(spath_raytracer_context *c)
+{
+    if (c->quiet) return;
+    c->span_marks[2 * c->span_count + 1] = rt_event_record(c->rctx->rcl->device);
+    c->span_count++;
+}
+
+static void span_reset(spath_raytracer_context *c)
+{
+    span_fold(c);
+    c->span_ms = 0.0;
+    c->span_launches = 0;
+}
+
 /* One rt_k_spath_run launch over iterations launched_upto+1 .. launched_upto+count; their random values are drawn
    here, in iteration order. */
 static void launch_iterations(spath_raytracer_context *c, unsigned int count)
@@ -179,9 +214,11 @@ static void launch_iterations(spath_raytracer_context *c, unsigned int count)
         c->cl_snapshot_buffer = rt_mem_alloc(dev, (size_t)c->snap_count * n * sizeof(vec4));
         c->snapshot_slots = c->snap_count;
     }
+    span_begin(c);
     rt_k_spath_run_snap(dev, &rctx->stat_scene->kdt->view, &b, n, count, d_values,
                         c->cl_pixel_cost_buffer, (reorder && c->order_valid) ? c->cl_pixel_order_buffer : NULL, c->schedule,
                         c->snap_count ? c->cl_snapshot_buffer : NULL, c->snap_count ? first - a + 1 : 0, r);
+    span_end(c);
     c->values_uploaded[slot] = rt_event_record(dev);      /* the launch has read the table once this marker is passed */
     if (reorder) update_pixel_order(c, count);
     c->launched_upto = last;
@@ -209,9 +246,26 @@ static void resolve_from(spath_raytracer_context *c, rt_mem accum)
     rt_mem_download(rctx->rcl->device, rctx->output_buffer, rctx->cl_output_buffer, (size_t)n * 4);
 }
 
+/* Launches run ahead of the calls that ask for their iterations; what the device holds is the state after iteration
+   launched_upto.  A caller that changes the plan while launches are ahead of it -- ends the render earlier than the
+   iterations already launched, or switches to one launch per kernel per iteration in mid-flight -- would be handed
+   frames with more iterations in them than it asked for: that is refused, loudly, like every other misuse. */
+static void refuse_if_ahead(const spath_raytracer_context *c, const char *who, const char *what)
+{
+    fprintf(stderr, "ERROR: %s: %s while iterations up to %u are already launched (the caller is at %u of %u); change it "
+                    "before the render starts, right after a prepass, or render with run_ahead = 0\n", who, what,
+            c->launched_upto, c->current_iteration, c->num_iterations);
+    exit(1);
+}
+
+/* The frame as the device holds it.  Between the library's resolve points that is only the caller's frame when no
+   launch has run ahead of its calls (run_ahead = 0, one launch per kernel per iteration, or a render that has reached
+   its end); otherwise the call is refused. */
 void spath_raytracer_resolve(spath_raytracer_context *c)
 {
     spath_raytracer_flush(c);
+    const unsigned int at = c->current_iteration < c->num_iterations ? c->current_iteration : c->num_iterations;
+    if (c->launched_upto > at) refuse_if_ahead(c, "spath_raytracer_resolve", "the frame was asked for between resolve points");
     resolve_from(c, c->cl_path_output_buffer);
 }
 
@@ -332,10 +386,7 @@ void spath_raytracer_prepass(spath_raytracer_context *c)
     c->order_valid = false;
     if (c->rng_mode == RT_RNG_LIBC) srand((unsigned int)rt_time_ms());
     c->start_time = rt_time_ms();
-    if (!c->quiet) {                 /* device times for the line printed at every resolve point */
-        rt_timing_enable(dev, 1);
-        rt_timing_reset(dev);
-    }
+    span_reset(c);
 
     rt_mem_zero(dev, c->cl_path_output_buffer, n16);
     raytracer_prepass(rctx);
@@ -366,7 +417,6 @@ void spath_raytracer_prepass(spath_raytracer_context *c)
     /* a decision taken for this scene and frame is kept across renders */
     if (!c->schedule_fixed && c->trial_state == 0) spath_raytracer_calibrate(c);
     rt_device_sync(dev);
-    if (!c->quiet) rt_timing_reset(dev);      /* the lines printed at the resolve points count the render's launches only */
 }
 
 /* reference: src/spath_raytracer.c:355-402 */
@@ -380,6 +430,9 @@ void spath_raytracer_render(spath_raytracer_context *c)
     spath_raytracer_fill_buffers(c, &b);
 
     c->current_iteration++;
+    if (c->launched_upto > c->num_iterations) refuse_if_ahead(c, "spath_raytracer_render", "num_iterations was lowered");
+    if (c->separate_kernels && c->launched_upto >= c->current_iteration)
+        refuse_if_ahead(c, "spath_raytracer_render", "separate_kernels was switched on");
     if (c->current_iteration > c->num_iterations) {
         /* the reference still steps the RNG buffer on this call (src/spath_raytracer.c:364-373) */
         spath_raytracer_flush(c);
@@ -394,9 +447,11 @@ void spath_raytracer_render(spath_raytracer_context *c)
 
     if (c->separate_kernels) {
         const uint32_t rv = next_random_value(c);
+        span_begin(c);
         rt_k_xorshift(dev, b.random, n);
         rt_k_kd_intersect(dev, &kdt->view, b.ray_o, b.ray_d, b.hits, n);
         rt_k_spath_trace(dev, &kdt->view, &b, n, rv, 0);
+        span_end(c);
         c->launched_upto = c->current_iteration;
     } else if (c->current_iteration > c->launched_upto) {
         /* running ahead: this call launches its iteration and the following ones; otherwise iterations are
@@ -407,35 +462,35 @@ void spath_raytracer_render(spath_raytracer_context *c)
 
     if (c->resolve_interval && c->current_iteration % c->resolve_interval == 0) {
         const unsigned int t0 = rt_time_ms();
-        uint64_t launches = 0;
+        unsigned int launches = 0;
         double run_ms = 0.0;
         if (!c->quiet) {
-            /* device time of the render kernel since the last line; the reference prints host times of its three
-               launches here (src/spath_raytracer.c:396-399): traversal and shading are one kernel in this library */
-            rt_device_sync(dev);
-            rt_timing_get(dev, RT_K_SPATH_RUN, &launches, &run_ms);
-            if (c->separate_kernels) {
-                double ms2 = 0.0;
-                rt_timing_get(dev, RT_K_KD_INTERSECT, &launches, &run_ms);
-                rt_timing_get(dev, RT_K_SPATH_TRACE, &launches, &ms2);
-                run_ms += ms2;
-            }
-            rt_timing_reset(dev);
+            /* device time of this context's render launches since the last line; the reference prints host times of
+               its three launches here (src/spath_raytracer.c:396-399): traversal and shading are one kernel in this
+               library (one marker pair per launch, or per iteration's three launches with separate_kernels) */
+            span_fold(c);
+            launches = c->span_launches;
+            run_ms = c->span_ms;
+            c->span_ms = 0.0;
+            c->span_launches = 0;
         }
         const unsigned int t1 = rt_time_ms();
         resolve_at(c, c->current_iteration);
         if (!c->quiet) {
             const unsigned int t2 = rt_time_ms(), el = t2 - c->start_time;
-            printf("collision+trace: %.1f (device, %llu launches), wait: %u, draw: %u    %u.%u/%u    %u:%u:%u\n", run_ms,
-                   (unsigned long long)launches, t1 - t0, t2 - t1, c->current_iteration / 4, c->current_iteration % 4,
+            printf("collision+trace: %.1f (device, %u launches), wait: %u, draw: %u    %u.%u/%u    %u:%u:%u\n", run_ms,
+                   launches, t1 - t0, t2 - t1, c->current_iteration / 4, c->current_iteration % 4,
                    c->num_iterations / 4, (el / 1000) / 60, (el / 1000) % 60, el % 1000);
         }
     }
 }
 
 /* ---- checkpoint / resume ------------------------------------------------------------------------------------ */
+#define RT_CHECKPOINT_VERSION 2u
 typedef struct {
     char     magic[8];                 /* "RTSPATH1" */
+    uint32_t version, header_bytes;    /* RT_CHECKPOINT_VERSION, sizeof(spath_checkpoint_header): a file written by a build
+                                          with another layout (or byte order: both fields would not match) is refused */
     uint32_t width, height;            /* local frame of the context */
     rt_rows  rows;                     /* which rows of the full frame they are */
     uint32_t num_tris, tree_bytes;     /* the scene the state belongs to */
@@ -462,6 +517,8 @@ static void checkpoint_header(spath_raytracer_context *c, spath_checkpoint_heade
     raytracer_context *rctx = c->rctx;
     memset(hd, 0, sizeof *hd);
     memcpy(hd->magic, "RTSPATH1", 8);
+    hd->version = RT_CHECKPOINT_VERSION;
+    hd->header_bytes = (uint32_t)sizeof *hd;
     hd->width = rctx->width;
     hd->height = rctx->height;
     raytracer_get_rows(rctx, &hd->rows);
@@ -488,6 +545,7 @@ int spath_raytracer_save(spath_raytracer_context *c, const char *path)
     size_t bytes[RT_CHECKPOINT_BUFFERS];
     checkpoint_buffers(c, mem, bytes);
     void *host = malloc(16 * (n ? n : 1));
+    if (!host) { fprintf(stderr, "spath_raytracer_save: out of host memory\n"); fclose(f); remove(path); return 3; }
     int bad = fwrite(&hd, sizeof hd, 1, f) != 1;
     for (int k = 0; k < RT_CHECKPOINT_BUFFERS && !bad; k++) {
         rt_mem_download(dev, host, mem[k], bytes[k] * n);
@@ -511,7 +569,10 @@ int spath_raytracer_restore(spath_raytracer_context *c, const char *path)
     size_t bytes[RT_CHECKPOINT_BUFFERS], total = sizeof hd;
     checkpoint_buffers(c, mem, bytes);
     for (int k = 0; k < RT_CHECKPOINT_BUFFERS; k++) total += bytes[k] * n;
-    int bad = fread(&hd, sizeof hd, 1, f) != 1 || memcmp(hd.magic, mine.magic, 8) != 0;
+    int bad = fread(&hd, sizeof hd, 1, f) != 1 || memcmp(hd.magic, mine.magic, 8) != 0 ||
+              hd.version != RT_CHECKPOINT_VERSION || hd.header_bytes != (uint32_t)sizeof hd;
+    if (!bad)       /* a damaged header: an iteration past the render's end, or an RNG mode that does not exist */
+        bad = hd.iteration > hd.num_iterations || (hd.rng_mode != RT_RNG_LIBC && hd.rng_mode != RT_RNG_SPLITMIX);
     if (!bad)
         bad = hd.width != mine.width || hd.height != mine.height || memcmp(&hd.rows, &mine.rows, sizeof hd.rows) != 0 ||
               hd.num_tris != mine.num_tris || hd.tree_bytes != mine.tree_bytes;
@@ -525,7 +586,7 @@ int spath_raytracer_restore(spath_raytracer_context *c, const char *path)
     void *host[RT_CHECKPOINT_BUFFERS] = { 0 };
     for (int k = 0; k < RT_CHECKPOINT_BUFFERS && !bad; k++) {
         host[k] = malloc(bytes[k] * (n ? n : 1));
-        bad = n && fread(host[k], bytes[k], n, f) != n;
+        bad = !host[k] || (n && fread(host[k], bytes[k], n, f) != n);
     }
     fclose(f);
     if (!bad) {
@@ -569,6 +630,7 @@ void spath_raytracer_destroy(spath_raytracer_context *c)
     if (c->cl_tile_scratch_buffer) rt_mem_free(dev, c->cl_tile_scratch_buffer);
     for (int k = 0; k < 2; k++)
         if (c->values_uploaded[k]) rt_event_release(dev, c->values_uploaded[k]);
+    span_fold(c);
     rt_host_free(dev, c->pending_values);
     free(c->random_buffer);
     free(c);

@@ -54,6 +54,7 @@ void rt_device_close(rt_device *dev)
     for (hipEvent_t e : dev->free_events) (void)hipEventDestroy(e);
     for (int i = 0; i < dev->num_streams; i++) RT_HIP_CHECK(hipStreamDestroy(dev->streams[i]));
     RT_HIP_CHECK(hipFree(dev->counters));
+    rt_kernels_release_device(dev);
     delete dev;
 }
 

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <map>
+#include <mutex>
 #include <vector>
 
 #include "rt_hip.h"
@@ -42,12 +43,15 @@ struct rt_device {
     // This GPU's copy of the kernels' file-scope scratch array (work counters of the entry point that allocates
     // nothing), resolved once by rt_kernels_setup_device, and that entry point's launch geometry.
     uint32_t *static_counters = nullptr;
+    int noalloc_slot = -1;          // which block of RT_MAX_STREAMS counter lines of that array is this device's (-1: none left)
     int noalloc_blocks_per_cu = 0;
     std::map<const void *, int> blocks_per_cu;   // resident one-wave blocks per CU of each persistent kernel on this device
 };
 
 // Per-device set-up of the kernel translation unit (called by rt_device_open with the device current).
 void rt_kernels_setup_device(rt_device *dev);
+// Gives back what set-up took from process-wide tables (called by rt_device_close).
+void rt_kernels_release_device(rt_device *dev);
 
 // Brackets one launch with events when timing is on.
 struct rt_launch_timer {

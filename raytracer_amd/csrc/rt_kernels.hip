@@ -1517,15 +1517,25 @@ void launch_spath_run(rt_device *dev, const TravScene &P, const SpathDev &B, uin
 
 // ---------------------------------------------------------------------------
 // Scratch memory of rt_k_kd_intersect_noalloc: the work counters its persistent
-// waves claim rays from, one 64-byte line per stream of an rt_device.  The array
+// waves claim rays from, one 64-byte line per stream of each rt_device that is
+// open on a GPU (up to RT_NOALLOC_DEVICES_PER_GPU of them at a time).  The array
 // lives in the code object, so every GPU the library runs on holds its own copy
-// (512 bytes) at its own address until the process ends.  In host code the name
+// (8 KB) at its own address until the process ends.  In host code the name
 // `scratch` is only a handle for hipGetSymbolAddress -- it is not a device
 // address and is never passed to a kernel, a memset or a copy: set-up resolves
 // it once per device into rt_device::static_counters and everything uses that.
+// An rt_device takes a block of RT_MAX_STREAMS lines of its GPU's array when it
+// is opened and gives it back when it is closed, so calls through different
+// rt_devices (which have different streams and may overlap on the GPU) never
+// share a counter.
 // ---------------------------------------------------------------------------
-#define RT_NOALLOC_SCRATCH_WORDS (16 * RT_MAX_STREAMS)
+#define RT_NOALLOC_DEVICES_PER_GPU 16
+#define RT_NOALLOC_MAX_GPUS 64
+#define RT_NOALLOC_SCRATCH_WORDS (16 * RT_MAX_STREAMS * RT_NOALLOC_DEVICES_PER_GPU)
 static __device__ __align__(256) uint32_t scratch[RT_NOALLOC_SCRATCH_WORDS];
+
+static std::mutex noalloc_slots_lock;
+static uint32_t noalloc_slots_taken[RT_NOALLOC_MAX_GPUS];     // per GPU ordinal: bit s = block s is held by an open rt_device
 
 void rt_kernels_setup_device(rt_device *dev)
 {
@@ -1533,10 +1543,30 @@ void rt_kernels_setup_device(rt_device *dev)
     void *p = nullptr;
     RT_HIP_CHECK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
     dev->static_counters = (uint32_t *)p;
-    RT_HIP_CHECK(hipMemset(dev->static_counters, 0, sizeof(uint32_t) * RT_NOALLOC_SCRATCH_WORDS));
+    dev->noalloc_slot = -1;
+    if (dev->ordinal < RT_NOALLOC_MAX_GPUS) {
+        std::lock_guard<std::mutex> hold(noalloc_slots_lock);
+        for (int s = 0; s < RT_NOALLOC_DEVICES_PER_GPU; s++)
+            if (!(noalloc_slots_taken[dev->ordinal] & (1u << s))) {
+                noalloc_slots_taken[dev->ordinal] |= 1u << s;
+                dev->noalloc_slot = s;
+                break;
+            }
+    }
+    if (dev->noalloc_slot >= 0)       // this device's lines only: other rt_devices on this GPU may be using theirs
+        RT_HIP_CHECK(hipMemset(dev->static_counters + 16 * RT_MAX_STREAMS * dev->noalloc_slot, 0,
+                               sizeof(uint32_t) * 16 * RT_MAX_STREAMS));
     // the launch geometry is asked for here so that the entry point itself calls nothing that may load or allocate
     RT_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&dev->noalloc_blocks_per_cu, k_kd_intersect<12, 16, 256>, 64, 0));
     if (dev->noalloc_blocks_per_cu < 1) dev->noalloc_blocks_per_cu = 1;
+}
+
+void rt_kernels_release_device(rt_device *dev)
+{
+    if (dev->noalloc_slot < 0 || dev->ordinal >= RT_NOALLOC_MAX_GPUS) return;
+    std::lock_guard<std::mutex> hold(noalloc_slots_lock);
+    noalloc_slots_taken[dev->ordinal] &= ~(1u << dev->noalloc_slot);
+    dev->noalloc_slot = -1;
 }
 
 extern "C" {
@@ -1597,6 +1627,11 @@ int rt_k_kd_intersect_noalloc(rt_device *dev, const rt_kd_view *kd, rt_mem ray_o
         fprintf(stderr, "ERROR: rt_k_kd_intersect_noalloc: no flattened kd-tree, or a null ray / hit buffer\n");
         return 2;
     }
+    if (dev->noalloc_slot < 0) {
+        fprintf(stderr, "ERROR: rt_k_kd_intersect_noalloc: more than %d rt_devices are open on GPU %d; this one has no "
+                        "counter lines in the library's static array\n", RT_NOALLOC_DEVICES_PER_GPU, dev->ordinal);
+        return 3;
+    }
     TravScene P;
     P.nodes = (const uint4 *)kd->nodes;
     P.leaf_tris = (const float4 *)kd->leaf_tris;
@@ -1608,8 +1643,8 @@ int rt_k_kd_intersect_noalloc(rt_device *dev, const rt_kd_view *kd, rt_mem ray_o
     unsigned grid = (unsigned)dev->noalloc_blocks_per_cu * (unsigned)dev->props.multiProcessorCount;
     const unsigned need = blocks_for(n, 64);
     if (grid > need) grid = need;
-    // the array keeps the last call's count: clear this stream's line, in stream order, before the launch
-    uint32_t *counter = dev->static_counters + 16 * dev->current;
+    // the array keeps the last call's count: clear this device's line for this stream, in stream order, before the launch
+    uint32_t *counter = dev->static_counters + 16 * (RT_MAX_STREAMS * dev->noalloc_slot + dev->current);
     RT_HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(uint32_t), dev->stream));
     hipLaunchKernelGGL((k_kd_intersect<12, 16, 256>), dim3(grid), dim3(64), 0, dev->stream, P, (const float4 *)ray_o,
                        (const float4 *)ray_d, (Hit *)hits, n, counter);

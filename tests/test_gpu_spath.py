@@ -524,6 +524,90 @@ def test_checkpoint_and_resume(rt, orc, small, tmp_path):
     assert c.L.spath_raytracer_restore(c.spath, b"/nonexistent/file") == 1
     assert c.spath.contents.current_iteration == 0
     c.close()
+    # damaged headers are refused (2) and leave the context alone: an iteration past the render's end, an RNG mode
+    # that does not exist, another layout version.  Header: magic[8], version, header_bytes, width, height, rows[4],
+    # num_tris, tree_bytes, iteration, num_iterations, rng_mode, ...
+    raw = bytearray(open(path.decode(), "rb").read())
+    words = np.frombuffer(bytes(raw[:96]), np.uint32).copy()
+    assert words[2] == 2 and words[3] == 84 and words[12] == 10 and words[13] == 16 and words[14] == rt.RT_RNG_SPLITMIX
+    d = rt.Renderer(sc, w, h).build()
+    d.init_spath(seed=seed, resolve_interval=0)
+    d.spath_prepass(num_iterations=3)
+    for index, value in ((12, 17), (14, 7), (2, 1), (3, 80)):
+        bad = words.copy()
+        bad[index] = value
+        damaged = str(tmp_path / f"damaged_{index}.ckpt")
+        with open(damaged, "wb") as f:
+            f.write(bad[:21].tobytes() + bytes(raw[84:]))
+        assert d.L.spath_raytracer_restore(d.spath, damaged.encode()) == 2, index
+        assert d.spath.contents.current_iteration == 0 and d.spath.contents.num_iterations == 3
+    d.close()
+
+
+def test_changing_the_plan_while_launches_are_ahead_is_refused(rt):
+    """Through the C API, as a reference-style caller would: with run_ahead the first render call launches the whole
+    render; lowering num_iterations below what is launched, switching to separate kernels, or asking for the frame
+    between resolve points would then hand over frames with iterations nobody asked for -- the library refuses
+    (message, exit status 1, the host API's error convention).  With run_ahead = 0 the same calls are fine."""
+    import subprocess
+    import sys
+    prog = """
+import sys
+sys.path.insert(0, {root!r})
+import raytracer_amd as rt
+sc = rt.scenes.icosphere_scene(3)
+r = rt.Renderer(sc, 64, 64).build()
+r.init_spath(seed=3, resolve_interval=50, run_ahead={ahead})
+r.L.spath_raytracer_prepass(r.spath)
+c = r.spath.contents
+c.num_iterations = 120
+r.L.spath_raytracer_render(r.spath)
+print("launched", c.launched_upto, flush=True)
+what = {what!r}
+if what == "lower":
+    c.num_iterations = 10
+    r.L.spath_raytracer_render(r.spath)
+elif what == "separate":
+    c.separate_kernels = 1
+    r.L.spath_raytracer_render(r.spath)
+elif what == "resolve":
+    r.L.spath_raytracer_resolve(r.spath)
+r.sync()
+print("survived", c.launched_upto, flush=True)
+"""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for what in ("lower", "separate", "resolve"):
+        for ahead in (1, 0):
+            p = subprocess.run([sys.executable, "-c", prog.format(root=root, ahead=ahead, what=what)],
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+            out, err = p.stdout.decode(), p.stderr.decode()
+            if ahead:
+                assert "launched 120" in out and "survived" not in out, (what, out, err[-500:])
+                assert p.returncode == 1 and "already launched" in err, (what, p.returncode, err[-500:])
+            else:
+                assert p.returncode == 0 and "launched 1" in out and "survived" in out, (what, out, err[-500:])
+
+
+def test_a_talking_context_leaves_the_device_timing_table_alone(rt, small, capfd):
+    """A context that prints the line at its resolve points (quiet = false) times its own launches with markers of
+    its own: the device-wide rt_timing_* table keeps what another user of the rt_device has collected in it."""
+    sc, _ = small
+    r = rt.Renderer(sc, 64, 64).build()
+    r.init_spath(seed=5, resolve_interval=50, quiet=False)
+    r.timing(True); r.timing_reset()
+    r.spath_prepass(num_iterations=120)
+    before, _ = r.timing_get("kd_intersect")
+    assert before == 1                                   # the prepass's traversal launch, counted by the table
+    r.spath_render(110)
+    r.sync()
+    launches, ms = r.timing_get("spath_run")
+    assert launches >= 1 and ms > 0                      # not cleared at the resolve points at iterations 50 and 100
+    assert r.timing_get("kd_intersect")[0] == 1
+    out = capfd.readouterr().out
+    assert out.count("collision+trace:") == 2 and "launches)" in out
+    r.timing(False)
+    r.close()
 
 
 def test_headless_event_protocol(rt, orc, tmp_path):

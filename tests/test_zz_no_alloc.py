@@ -58,3 +58,77 @@ def test_noalloc_traversal_equals_allocating_entry_point(rt, orc):
         for m in (ro, rd, h_a, h_b):
             r.L.rt_mem_free(r.dev, m)
         r.close()
+
+
+def test_two_devices_on_one_gpu_have_counters_of_their_own(rt, orc):
+    """Two rt_devices opened on the same GPU (two Renderers) call the entry point at the same time: each has its
+    own counter lines in the GPU's static array, so neither call clears the counter the other's waves claim rays
+    from -- every ray of both calls gets its hit record (the calls are queued without a host synchronisation
+    between them, on the two devices' own streams, several times over)."""
+    sc = rt.scenes.icosphere_scene(4)
+    a = rt.Renderer(sc, 8, 8).build(); a.L.raytracer_prepass(a.rctx)
+    b = rt.Renderer(sc, 8, 8).build(); b.L.raytracer_prepass(b.rctx)
+    n = 200_000
+    rays = _rays(n, 21)
+    bufs = []
+    try:
+        for r in (a, b):
+            ro = r.L.rt_mem_alloc(r.dev, 16 * n); rd = r.L.rt_mem_alloc(r.dev, 16 * n)
+            want = r.L.rt_mem_alloc(r.dev, 16 * n); got = r.L.rt_mem_alloc(r.dev, 16 * n)
+            r.upload(ro, np.ascontiguousarray(rays[:, 0:4])); r.upload(rd, np.ascontiguousarray(rays[:, 4:8]))
+            r.L.rt_k_kd_intersect(r.dev, C.byref(r.kdt.view), ro, rd, want, n)
+            bufs.append((r, ro, rd, want, got))
+        a.sync(); b.sync()
+        for rep in range(6):
+            for r, ro, rd, want, got in bufs:
+                r.L.rt_mem_zero(r.dev, got, 16 * n)
+            for r, ro, rd, want, got in bufs:            # queued back to back: the two launches overlap on the GPU
+                assert r.L.rt_k_kd_intersect_noalloc(r.dev, C.byref(r.kdt.view), ro, rd, got, n) == 0
+            for r, ro, rd, want, got in bufs:
+                r.sync()
+                assert_bits_equal(r.download(got, np.uint32, 4 * n), r.download(want, np.uint32, 4 * n),
+                                  f"hit records, round {rep}")
+    finally:
+        for r, *mems in bufs:
+            for m in mems:
+                r.L.rt_mem_free(r.dev, m)
+        a.close(); b.close()
+
+
+def test_device_without_counter_lines_is_refused_not_shared(rt):
+    """The static array holds counter lines for 16 rt_devices per GPU: a device opened while 16 others are open
+    gets none and its calls return 3 (nothing launched); closing a device frees its lines for the next one."""
+    L = rt.lib()
+    sc = rt.scenes.icosphere_scene(2)
+    r = rt.Renderer(sc, 8, 8).build(); r.L.raytracer_prepass(r.rctx)
+    view = C.byref(r.kdt.view)                  # device memory of GPU 0: any rt_device on it can traverse the tree
+    ro = L.rt_mem_alloc(r.dev, 1024); rd = L.rt_mem_alloc(r.dev, 1024); h = L.rt_mem_alloc(r.dev, 1024)
+    L.rt_mem_zero(r.dev, ro, 1024); L.rt_mem_zero(r.dev, rd, 1024)
+    r.sync()
+    devs, refused = [], None
+    try:
+        assert L.rt_k_kd_intersect_noalloc(r.dev, view, ro, rd, h, 64) == 0
+        for _ in range(16):                     # other tests may hold devices too: the 16th open at the latest is refused
+            d = L.rt_device_open(0)
+            devs.append(d)
+            rc = L.rt_k_kd_intersect_noalloc(d, view, ro, rd, h, 64)
+            L.rt_device_sync(d)
+            if rc == 3:
+                refused = d
+                break
+            assert rc == 0
+        assert refused is not None
+        assert L.rt_k_kd_intersect_noalloc(refused, view, ro, rd, None, 64) == 2      # argument checks come first
+        L.rt_device_close(devs.pop(0))          # gives its lines back
+        extra = L.rt_device_open(0)
+        devs.append(extra)
+        assert L.rt_k_kd_intersect_noalloc(extra, view, ro, rd, h, 64) == 0
+        L.rt_device_sync(extra)
+        assert L.rt_k_kd_intersect_noalloc(refused, view, ro, rd, h, 64) == 3        # decided when it was opened
+    finally:
+        for d in devs:
+            L.rt_device_close(d)
+        r.sync()
+        for m in (ro, rd, h):
+            L.rt_mem_free(r.dev, m)
+        r.close()
