@@ -586,7 +586,8 @@ print("survived", c.launched_upto, flush=True)
                 assert "launched 120" in out and "survived" not in out, (what, out, err[-500:])
                 assert p.returncode == 1 and "already launched" in err, (what, p.returncode, err[-500:])
             else:
-                assert p.returncode == 0 and "launched 1" in out and "survived" in out, (what, out, err[-500:])
+                # nothing is launched beyond what was asked for (iterations are collected, or launched one by one)
+                assert p.returncode == 0 and "launched 120" not in out and "survived" in out, (what, out, err[-500:])
 
 
 def test_a_talking_context_leaves_the_device_timing_table_alone(rt, small, capfd):
