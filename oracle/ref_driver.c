@@ -9,8 +9,10 @@
  * ask the real builder + serialiser for a tree blob.  The output library goes
  * to oracle/_ref/ and is never committed.
  *
- * Only the host-side builder can be built this way.  The device kernels are
- * OpenCL C and need a built-in library this image does not have.
+ * This file covers the host-side builder only.  The reference's device kernels
+ * (OpenCL C) are built separately, unmodified, for gfx950 with ROCm's clang and
+ * ROCm's own OpenCL built-in library by oracle/build_ref_kernels.py, and are
+ * launched by oracle/hsa_runner.c + oracle/refcl.py.
  */
 #define CL_TARGET_OPENCL_VERSION 120
 #include <assert.h>

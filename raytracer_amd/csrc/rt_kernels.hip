@@ -463,53 +463,6 @@ __device__ __forceinline__ bool walk_leaf_load(const TravScene &P, Walk &w, f3 o
     return walk_leaf<LDS_DEPTH>(P, w, o, d, T0, T1, T2, col, spill, in_leaf, has);
 }
 
-// One trip of the walk with ONE memory round trip: the lanes standing on an interior node fetch its record, the
-// lanes standing in a leaf fetch their next triangle, and a lane about to use up its leaf (this is its last
-// triangle, or the leaf is empty) also fetches the record of the node it will continue at if the ray does not end
-// here -- the far child on top of its stack, or the root for a restart -- all in one batch of loads.  Then the
-// triangle is tested and the lanes whose leaf is used up pop; then every lane that holds the record of the node it
-// stands on descends (up to two levels).  A lane thus takes "descend", "triangle" or "triangle, pop, descend" per
-// round trip, where fetching records and triangles in two slots takes two dependent round trips per trip.  The
-// decisions are those of walk_descend / walk_leaf_step, so results do not depend on which form runs.
-template <int LDS_DEPTH>
-__device__ __forceinline__ bool walk_trip_fused(const TravScene &P, Walk &w, f3 o, f3 d, f3 rd, bool plain,
-                                                uint2 *__restrict__ col, uint2 *__restrict__ spill, bool walking,
-                                                uint32_t &steps)
-{
-    const bool in_leaf = walking & ((w.ref & RT_REF_LEAF) != 0u);
-    const bool in_node = walking & !(w.ref & RT_REF_LEAF);
-    steps += walking ? 1u : 0u;
-
-    const bool first = w.li == 0u;
-    const uint32_t count = RT_REF_COUNT(w.ref);
-    w.lc = first ? count : w.lc;
-    const bool has = in_leaf & (w.li < w.lc);
-    // a long leaf keeps its count in its header slot: not known before that arrives, and never used up by it
-    const bool leaving = in_leaf & !(first & (count == 31u)) & (w.li + 1u >= w.lc);
-    const PopData pd = walk_peek<LDS_DEPTH>(P, w, col, spill, leaving & (w.sp != 0u));
-    const bool ahead = leaving & !(pd.e.x & RT_REF_LEAF);          // continues at an interior node: fetch it now
-
-    uint4 a, r;
-    LeafSlot t;
-    undefined_words(a); undefined_words(r); undefined_words(t.a); undefined_words(t.b); undefined_words(t.c);
-    if (in_node | ahead) {
-        const uint32_t top = (in_node ? w.ref : pd.e.x) & ~3u;
-        const uint4 *rec = (const uint4 *)((const char *)P.nodes + (top << 3));
-        a = rec[0]; r = rec[1];
-    }
-    if (has) t = leaf_slot_load(P, w);
-    // all five loads leave here, together, before anything waits for one of them
-    asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(r.x), "+v"(r.y), "+v"(r.z), "+v"(r.w));
-    asm volatile("" : "+v"(t.a.x), "+v"(t.a.y), "+v"(t.a.z), "+v"(t.a.w), "+v"(t.b.x), "+v"(t.b.y), "+v"(t.b.z), "+v"(t.b.w),
-                      "+v"(t.c.x), "+v"(t.c.y));
-    w.lc = (first & (count == 31u)) ? t.c.y : w.lc;
-    const float4 T0 = leaf_slot_v0(t), T1 = leaf_slot_e1(t), T2 = leaf_slot_e2(t);
-    bool moved;
-    const bool fin = walk_leaf_step<LDS_DEPTH>(P, w, o, d, T0, T1, T2, pd, in_leaf, has, moved);
-    walk_record_steps<LDS_DEPTH>(w, o, d, rd, plain, a, r, col, spill, in_node | (moved & ahead));
-    return fin;
-}
-
 __device__ __forceinline__ Hit walk_result(const Walk &w)
 {
     Hit h;
@@ -548,7 +501,7 @@ __device__ __forceinline__ uint32_t queue_take(WorkQueue &q, bool want, uint32_t
 }
 
 // kdtree_intersection: every ray of ray_o/ray_d[0..n) -> hits[0..n).
-template <int LDS_DEPTH, int REFILL_MIN, int CHUNK, bool FUSED = false>
+template <int LDS_DEPTH, int REFILL_MIN, int CHUNK>
 __global__ __launch_bounds__(64) void k_kd_intersect(TravScene P, const float4 *__restrict__ ray_o,
                                                      const float4 *__restrict__ ray_d, Hit *__restrict__ hits,
                                                      uint32_t n, uint32_t *__restrict__ counter)
@@ -578,14 +531,6 @@ __global__ __launch_bounds__(64) void k_kd_intersect(TravScene P, const float4 *
         }
         if (!__any(walking)) {
             if (q.exhausted) break;
-            continue;
-        }
-        if (FUSED) {
-            uint32_t steps = 0;
-            if (walk_trip_fused<LDS_DEPTH>(P, w, o, d, rd, plain, col, spill, walking, steps)) {
-                hits[ridx] = walk_result(w);
-                walking = false;
-            }
             continue;
         }
         // one record (up to two descend steps) for the lanes on interior nodes,
@@ -935,11 +880,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
 #endif
         if (!__any(mode == WALK)) {
             if (q.exhausted && !__any(mode == DONE)) break;
-            continue;
-        }
-        if (NI == 0) {       // one round trip per trip: walk_trip_fused
-            const bool fin = walk_trip_fused<LDS_DEPTH>(P, w, o, d, rd, plain, col, spill, mode == WALK, steps);
-            mode = fin ? (uint32_t)DONE : mode;
             continue;
         }
         // up to NI records (two descend steps each), then up to NT triangles: a
@@ -1400,10 +1340,10 @@ int resident_blocks_per_cu(rt_device *dev, K kern)
 // as the chip keeps resident for this kernel (LDS-limited), never more than
 // there are 64-ray groups.  RT_TRAVERSE_VARIANT (environment, read once)
 // selects one of a few compiled parameter sets for tuning runs.
-template <int LDS_DEPTH, int REFILL_MIN, int CHUNK, bool FUSED = false>
+template <int LDS_DEPTH, int REFILL_MIN, int CHUNK>
 void launch_kd_variant(rt_device *dev, const TravScene &P, const float4 *ro, const float4 *rd, Hit *hits, uint32_t n)
 {
-    auto kern = k_kd_intersect<LDS_DEPTH, REFILL_MIN, CHUNK, FUSED>;
+    auto kern = k_kd_intersect<LDS_DEPTH, REFILL_MIN, CHUNK>;
     RT_HIP_CHECK(hipSetDevice(dev->ordinal));
     const int blocks_per_cu = resident_blocks_per_cu(dev, kern);
     static int waves_per_cu = -1;
@@ -1431,8 +1371,6 @@ void launch_kd_intersect(rt_device *dev, const TravScene &P, const float4 *ro, c
     }
     switch (variant) {
     case 1: launch_kd_variant<16, 16, 256>(dev, P, ro, rd, hits, n); break;
-    case 2: launch_kd_variant<8, 16, 256>(dev, P, ro, rd, hits, n); break;
-    case 3: launch_kd_variant<12, 16, 256, true>(dev, P, ro, rd, hits, n); break;
     default: launch_kd_variant<12, 16, 256>(dev, P, ro, rd, hits, n); break;
     }
 }
@@ -1479,33 +1417,14 @@ void launch_spath_run(rt_device *dev, const TravScene &P, const SpathDev &B, uin
         launch_run_variant<16, 16, 64, 3, 3, 4>(dev, P, B, n, iters, rv, snap_first, snap_every);
         return;
     }
+    // the sets a sweep over the benchmark's workloads has favoured somewhere, beside the four schedules
     switch (variant) {
-    case 1: launch_run_variant<10, 16, 64, 2, 1, 7>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
-    case 2: launch_run_variant<10, 8, 64, 1, 1, 7>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
-    case 3: launch_run_variant<10, 24, 64, 1, 1, 7>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
-    case 4: launch_run_variant<10, 32, 64, 1, 1, 7>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
-    case 5: launch_run_variant<8, 16, 64, 1, 1, 7>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
-    case 6: launch_run_variant<10, 12, 64, 1, 1, 7>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
-    case 7: launch_run_variant<10, 20, 64, 1, 1, 7>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
-    case 8: launch_run_variant<12, 16, 64, 1, 2, 6>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
-    case 9: launch_run_variant<12, 16, 64, 1, 2, 5>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
-    case 10: launch_run_variant<12, 16, 64, 2, 2, 5>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
-    case 11: launch_run_variant<10, 16, 64, 1, 1, 8>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
-    case 12: launch_run_variant<8, 16, 64, 1, 1, 8>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
-    case 13: launch_run_variant<10, 16, 64, 1, 1, 6>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
-    case 14: launch_run_variant<10, 16, 64, 1, 2, 7>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
+    case 7: launch_run_variant<10, 20, 64, 1, 1, 7>(dev, P, B, n, iters, rv, snap_first, snap_every); break;    // shading at 20 waiting lanes
+    case 11: launch_run_variant<10, 16, 64, 1, 1, 8>(dev, P, B, n, iters, rv, snap_first, snap_every); break;   // 8 waves per SIMD
+    case 14: launch_run_variant<10, 16, 64, 1, 2, 7>(dev, P, B, n, iters, rv, snap_first, snap_every); break;   // one descend, two leaf slots
     case 15: launch_run_variant<10, 16, 64, 2, 2, 7>(dev, P, B, n, iters, rv, snap_first, snap_every); break;   // = RT_SCHEDULE_TWO_AND_TWO
-    case 16: launch_run_variant<11, 16, 64, 1, 1, 7>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
     case 17: launch_run_variant<16, 16, 64, 2, 2, 5>(dev, P, B, n, iters, rv, snap_first, snap_every); break;   // = RT_SCHEDULE_SHORT_CHAINS
-    case 19: launch_run_variant<16, 16, 64, 1, 1, 5>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
-    case 20: launch_run_variant<10, 16, 64, 0, 0, 7>(dev, P, B, n, iters, rv, snap_first, snap_every); break;   // one round trip per trip
-    case 21: launch_run_variant<10, 16, 64, 0, 0, 6>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
-    case 22: launch_run_variant<12, 16, 64, 0, 0, 6>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
-    case 23: launch_run_variant<10, 16, 64, 0, 0, 8>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
-    case 24: launch_run_variant<16, 16, 64, 0, 0, 5>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
-    case 25: launch_run_variant<16, 16, 64, 2, 2, 4>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
-    case 26: launch_run_variant<16, 16, 64, 2, 2, 3>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
-    case 27: launch_run_variant<16, 16, 64, 1, 1, 4>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
+    case 25: launch_run_variant<16, 16, 64, 2, 2, 4>(dev, P, B, n, iters, rv, snap_first, snap_every); break;   // short chains at 4 waves per SIMD
     case 28: launch_run_variant<16, 16, 64, 3, 3, 4>(dev, P, B, n, iters, rv, snap_first, snap_every); break;   // = RT_SCHEDULE_THREE_AND_THREE
     default: launch_run_variant<10, 16, 64, 1, 1, 7>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
     }
