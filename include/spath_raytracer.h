@@ -19,7 +19,8 @@ enum {
 };
 
 #define RT_SPAN_MAX 64      /* render launches whose device time is pending between two resolve-point lines */
-#define RT_TRIAL_PARTS 5   /* timed launches of a calibration: default schedule, three alternatives, default */
+#define RT_TRIAL_PARTS 5   /* timed launches of a calibration: default schedule (two and two slots), the three others (one
+                              and one, short chains, three and three), default again */
 
 typedef struct spath_raytracer_context {
     struct _rt_ctx *rctx;
