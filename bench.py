@@ -509,7 +509,7 @@ def main():
             try:
                 q = json.load(open(quoted))
                 parity["quoted_full_render_vs_reference_kernels"] = {
-                    "source": os.path.relpath(quoted, ROOT), "measured": "round 2 (2026-11), not in this run",
+                    "source": os.path.relpath(quoted, ROOT), "measured": "2026-11 by tests/tools/ref_kernels_parity.py, not in this run",
                     "iterations": q["iterations"], "radiance_rmse": q["radiance_rmse"],
                     "pixels_left_out_reference_stack_overflow": q["pixels_left_out"],
                     "pixels_within_1e-3": q["pixels_within_1e-3"]}

@@ -1487,6 +1487,13 @@ void launch_spath_run(rt_device *dev, const TravScene &P, const SpathDev &B, uin
     case 17: launch_run_variant<16, 16, 64, 2, 2, 5>(dev, P, B, n, iters, rv, snap_first, snap_every); break;   // = RT_SCHEDULE_SHORT_CHAINS
     case 25: launch_run_variant<16, 16, 64, 2, 2, 4>(dev, P, B, n, iters, rv, snap_first, snap_every); break;   // short chains at 4 waves per SIMD
     case 28: launch_run_variant<16, 16, 64, 3, 3, 4>(dev, P, B, n, iters, rv, snap_first, snap_every); break;   // = RT_SCHEDULE_THREE_AND_THREE
+#ifdef RT_EXP_MORE_SLOTS      /* tuning builds: more slots per trip at the default occupancy */
+    case 40: launch_run_variant<10, 16, 64, 3, 3, 7>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
+    case 41: launch_run_variant<10, 16, 64, 2, 3, 7>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
+    case 42: launch_run_variant<10, 16, 64, 3, 2, 7>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
+    case 43: launch_run_variant<10, 16, 64, 4, 4, 7>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
+    case 44: launch_run_variant<10, 16, 64, 3, 3, 6>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
+#endif
     default: launch_run_variant<10, 16, 64, 1, 1, 7>(dev, P, B, n, iters, rv, snap_first, snap_every); break;
     }
 }
