@@ -776,11 +776,13 @@ struct SpathDev {
 #define RT_IT_SLOT_SHIFT 11
 #define RT_IT_LEFT_SHIFT 16
 #define RT_IT_FINISHED_ONE 0xffff0001u   /* +1 finished, -1 left */
+#define RT_HANDOVER_GROUPS_UPTO 40u      /* launches of at most this many iterations hand pixels over in groups */
+#define RT_HANDOVER_WAIT 16u             /* trips a finished pixel is held at most while its group fills */
 
 template <int LDS_DEPTH, int SHADE_MIN, int CHUNK, int NI, int NT, int WAVES>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_spath_run(TravScene P, SpathDev B, uint32_t n, uint32_t iters,
                                                   const uint32_t *__restrict__ rv, uint32_t *__restrict__ counter,
-                                                  uint32_t snap_first, uint32_t snap_every)
+                                                  uint32_t snap_first, uint32_t snap_every, uint32_t handover_min)
 {
     __shared__ uint2 stack[LDS_DEPTH * 64];
     uint2 spill[RT_MAX_STACK - LDS_DEPTH];
@@ -790,7 +792,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
     // jump would cost a register copy per state word on every trip.
     constexpr bool SKIP_EMPTY = (NI + NT) > 2;
 
-    enum { FREE = 0, WALK = 1, DONE = 2 };
+    enum { FREE = 0, WALK = 1, DONE = 2, LAST = 3 };     // LAST: the pixel's last iteration is done, its state not stored yet
+    // A lane that has finished its pixel keeps it until handover_min lanes of the wave have, but for handover_wait
+    // trips at most (or until nothing else is left to do): a hand-over makes the whole wave wait three times for
+    // memory (the stores' acknowledgements, which the next loads wait for as well; the pixel-order lookup; the new
+    // pixel's state), and that is paid once per group.  The launcher asks for groups in short launches only, in which a
+    // wave hands a pixel over every few trips; in long ones the lanes finish too far apart and would only idle.
+    constexpr uint32_t handover_wait = RT_HANDOVER_WAIT;
+    uint32_t held = 0;           // trips since a lane of the wave began to hold a finished pixel (wave-uniform)
     WorkQueue q;
     Walk w = {};
     f3 o = mk3(0.f, 0.f, 0.f), d = o, rd = o;
@@ -810,9 +819,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
     for (;;) {
         const uint32_t ndone = (uint32_t)__popcll(__ballot(mode == DONE));
         const uint32_t nfree = (uint32_t)__popcll(__ballot(mode == FREE));
-        const uint32_t nwalk = 64u - ndone - nfree;
-        const uint32_t waiting = ndone + (q.exhausted ? 0u : nfree);
-        if (waiting >= (uint32_t)SHADE_MIN || (nwalk == 0 && waiting > 0)) {
+        const uint32_t nlast = (uint32_t)__popcll(__ballot(mode == LAST));
+        const uint32_t nwalk = 64u - ndone - nfree - nlast;
+        held = nlast ? held + 1u : 0u;
+        const bool hand_over = nlast >= handover_min || held > handover_wait;
+        const uint32_t waiting = ndone + (hand_over ? nlast : 0u) + (q.exhausted ? 0u : nfree);
+        if (waiting >= (uint32_t)SHADE_MIN || (nwalk == 0 && (waiting > 0 || nlast > 0))) {
             bool fresh = false;          // lane holds a new ray in w.o / w.d
             // (a) finish the iteration of lanes whose walk has ended
             if (mode == DONE) {
@@ -863,17 +875,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                     }
                 }
 #endif
-                if ((it & RT_IT_MASK) == iters) {       // leave the buffers as the last per-iteration launches would
-                    B.ray_o[pix] = mk4(o, 0.f);
-                    B.ray_d[pix] = mk4(d, 0.f);
-                    B.prog_a[pix] = pa;
-                    B.prog_b[pix] = pb;
-                    B.random[pix] = rnd;
-                    B.hits[pix] = h;
-                    B.cost[pix] = steps;
-                    mode = FREE;
-                } else {
-                    fresh = true;
+                if ((it & RT_IT_MASK) == iters) mode = LAST;
+                else fresh = true;
+            }
+            // (a') lanes that are through with their pixel hand it back, in groups: the buffers are left as the last
+            // per-iteration launches would leave them (the walk's registers still hold the last hit)
+            {
+                const uint32_t through = (uint32_t)__popcll(__ballot(mode == LAST));
+                const bool others_busy = __any((mode == WALK) | fresh);
+                if (through >= handover_min || held > handover_wait || (through > 0 && !others_busy)) {
+                    if (mode == LAST) {
+                        B.ray_o[pix] = mk4(o, 0.f);
+                        B.ray_d[pix] = mk4(d, 0.f);
+                        B.prog_a[pix] = pa;
+                        B.prog_b[pix] = pb;
+                        B.random[pix] = rnd;
+                        B.hits[pix] = walk_result(w);
+                        B.cost[pix] = steps;
+                        mode = FREE;
+                    }
                 }
             }
             // (b) free lanes take the next pixels
@@ -909,7 +929,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         }
 #endif
         if (!__any(mode == WALK)) {
-            if (q.exhausted && !__any(mode == DONE)) break;
+            if (q.exhausted && !__any((mode == DONE) | (mode == LAST))) break;
             continue;
         }
         // up to NI records (two descend steps each), then up to NT triangles: a
@@ -1452,7 +1472,13 @@ void launch_run_variant(rt_device *dev, const TravScene &P, const SpathDev &B, u
     uint32_t *counter = dev->counters + 16 * dev->current;
     RT_HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(uint32_t), dev->stream));
     rt_launch_timer tm(dev, RT_K_SPATH_RUN);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, dev->stream, P, B, n, iters, rv, counter, snap_first, snap_every);
+    // pixels change hands in groups of up to 8 lanes in launches of few iterations, one by one in long ones (see
+    // k_spath_run); RT_HANDOVER (environment, tuning): the group size
+    uint32_t handover = iters <= RT_HANDOVER_GROUPS_UPTO ? 8u : 1u;
+    static int handover_env = -2;
+    if (handover_env == -2) { const char *e = getenv("RT_HANDOVER"); handover_env = e ? atoi(e) : -1; }
+    if (handover_env >= 0) handover = (uint32_t)handover_env;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, dev->stream, P, B, n, iters, rv, counter, snap_first, snap_every, handover);
     RT_HIP_CHECK(hipGetLastError());
 }
 
