@@ -504,12 +504,14 @@ def main():
         out["parity"] = parity
         # the target render (256 samples x 4 bounces = 1024 iterations) against the reference's own kernels on this
         # GPU model: a stored, dated figure of tests/tools/ref_kernels_parity.py (minutes of run time), quoted here
-        quoted = os.path.join(ROOT, "profiles", "r02", f"{args.workload}_full_size_parity_1024_iterations.json")
-        if isinstance(parity, dict) and os.path.exists(quoted):
+        import glob
+        found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"{args.workload}_full_size_parity_1024_iterations.json")))
+        quoted = found[-1] if found else ""
+        if isinstance(parity, dict) and quoted:
             try:
                 q = json.load(open(quoted))
                 parity["quoted_full_render_vs_reference_kernels"] = {
-                    "source": os.path.relpath(quoted, ROOT), "measured": "2026-11 by tests/tools/ref_kernels_parity.py, not in this run",
+                    "source": os.path.relpath(quoted, ROOT), "measured": "by tests/tools/ref_kernels_parity.py (minutes of run time), not in this run",
                     "iterations": q["iterations"], "radiance_rmse": q["radiance_rmse"],
                     "pixels_left_out_reference_stack_overflow": q["pixels_left_out"],
                     "pixels_within_1e-3": q["pixels_within_1e-3"]}
