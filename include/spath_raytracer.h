@@ -52,7 +52,7 @@ typedef struct spath_raytracer_context {
     int          separate_kernels;    /* 1: three launches per iteration, as the reference; 0: iterations are batched
                                          into multi-iteration launches (rt_k_spath_run) */
     bool         quiet;
-    unsigned int max_batch;           /* most iterations folded into one launch; 0 = four resolve intervals (64 when
+    unsigned int max_batch;           /* most iterations folded into one launch; 0 = eight resolve intervals (64 when
                                          resolve_interval is 0), at most RT_RUN_MAX_ITERS */
     unsigned int pending;             /* iterations accepted by spath_raytracer_render but not launched yet */
     unsigned int *pending_values;     /* random values of the launches being put together: two tables of RT_RUN_MAX_ITERS
